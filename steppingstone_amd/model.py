@@ -1,0 +1,251 @@
+"""Robot model definitions (Walker3D, Mike) for the stepping-stone environments.
+
+The reference's robot assets live in the un-vendored `mocca_envs` submodule
+(/root/reference/.gitmodules:1-3) and are NOT available; the only facts the
+reference pins are the 21-joint action order (common/render_utils.py:47-69) and
+the obs/action dims 60/21 (shipped checkpoints).  Everything
+numeric below (link geometry, masses, ranges, gains) is THIS repository's own
+specification, documented in docs/PHYSICS.md §2.
+
+The model is a floating base (torso, body 0) plus 21 single-DoF revolute links.
+Multi-DoF anatomical joints (hip x/z/y, shoulder x/z/y, abdomen z/y) are chains of
+co-located revolute joints with massless intermediate links.  All link frames are
+axis-aligned with the torso frame at q = 0 (x forward, y left, z up); each joint
+rotates about one coordinate axis of its own link frame.
+
+`build(kind)` returns a dict of numpy arrays; `tools/gen_model_tables.py` turns it
+into the constexpr tables compiled into the HIP kernels and the plain-C tables
+used by the CPU oracle (data only — no algorithm is shared).
+"""
+import numpy as np
+
+NJ = 21          # actuated joints == non-root links
+NB = NJ + 1      # bodies including the torso (body 0)
+DENSITY = 1000.0
+
+JOINT_NAMES = [
+    "abdomen_z", "abdomen_y", "abdomen_x",
+    "right_hip_x", "right_hip_z", "right_hip_y", "right_knee", "right_ankle",
+    "left_hip_x", "left_hip_z", "left_hip_y", "left_knee", "left_ankle",
+    "right_shoulder_x", "right_shoulder_z", "right_shoulder_y", "right_elbow",
+    "left_shoulder_x", "left_shoulder_z", "left_shoulder_y", "left_elbow",
+]
+
+# parent BODY index of joint j's child link (child link of joint j is body j+1)
+PARENT = [0, 1, 2,
+          3, 4, 5, 6, 7,
+          3, 9, 10, 11, 12,
+          0, 14, 15, 16,
+          0, 18, 19, 20]
+# rotation axis of joint j in its own link frame: 0=x 1=y 2=z
+AXIS = [2, 1, 0,
+        0, 2, 1, 1, 1,
+        0, 2, 1, 1, 1,
+        0, 2, 1, 1,
+        0, 2, 1, 1]
+RIGHT_FOOT_BODY = 8    # child of right_ankle (joint 7)
+LEFT_FOOT_BODY = 13    # child of left_ankle  (joint 12)
+
+# joints whose sign flips under a left/right mirror (rotations about x or z), and the
+# right/left pairs that swap; the spine's z and x joints negate in place.
+MIRROR_NEGATE_JOINTS = [0, 2, 3, 4, 8, 9, 13, 14, 17, 18]
+MIRROR_RIGHT_JOINTS = [3, 4, 5, 6, 7, 13, 14, 15, 16]
+MIRROR_LEFT_JOINTS = [8, 9, 10, 11, 12, 17, 18, 19, 20]
+
+
+# ---------------------------------------------------------------- geometry helpers
+def _sphere(c, r):
+    m = DENSITY * 4.0 / 3.0 * np.pi * r ** 3
+    return m, np.asarray(c, float), np.eye(3) * (0.4 * m * r * r)
+
+
+def _box(c, half):
+    hx, hy, hz = half
+    m = DENSITY * 8 * hx * hy * hz
+    I = np.diag([m / 3 * (hy * hy + hz * hz), m / 3 * (hx * hx + hz * hz), m / 3 * (hx * hx + hy * hy)])
+    return m, np.asarray(c, float), I
+
+
+def _capsule(p0, p1, r):
+    p0 = np.asarray(p0, float)
+    p1 = np.asarray(p1, float)
+    L = np.linalg.norm(p1 - p0)
+    a = (p1 - p0) / L
+    mc = DENSITY * np.pi * r * r * L
+    ms = DENSITY * 4.0 / 3.0 * np.pi * r ** 3
+    i_ax = 0.5 * mc * r * r + 0.4 * ms * r * r
+    i_tr = mc * (3 * r * r + L * L) / 12.0 + ms * (0.4 * r * r + 0.25 * L * L + 0.375 * r * L)
+    aa = np.outer(a, a)
+    I = i_ax * aa + i_tr * (np.eye(3) - aa)
+    return mc + ms, 0.5 * (p0 + p1), I
+
+
+def _compose(geoms):
+    """mass, com, inertia about the LINK ORIGIN (link-frame axes)."""
+    if not geoms:
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+    m = sum(g[0] for g in geoms)
+    com = sum(g[0] * g[1] for g in geoms) / m
+    Io = np.zeros((3, 3))
+    for gm, gc, gI in geoms:
+        Io += gI + gm * (np.dot(gc, gc) * np.eye(3) - np.outer(gc, gc))
+    return m, com, Io
+
+
+def _deg(lo, hi):
+    return [np.deg2rad(lo), np.deg2rad(hi)]
+
+
+# ---------------------------------------------------------------- robot definitions
+def _humanoid(scale_leg, scale_arm, torso_w, mass_scale, gains, z_extra_head):
+    """Shared topology; dimension knobs distinguish Walker3D from Mike."""
+    g = {}          # body -> list of geoms
+    r = np.zeros((NJ, 3))
+    # ---- torso (body 0): chest capsule across y, head, upper waist
+    g[0] = [
+        _capsule([0, -torso_w, 0], [0, torso_w, 0], 0.07),
+        _sphere([0, 0, 0.19 + z_extra_head], 0.09 + z_extra_head * 0.5),
+        _capsule([-0.01, -0.06, -0.12], [-0.01, 0.06, -0.12], 0.06),
+    ]
+    # ---- spine: abdomen_z (massless) -> abdomen_y (lwaist) -> abdomen_x (pelvis)
+    r[0] = [-0.01, 0, -0.195]
+    g[1] = []
+    r[1] = [0, 0, 0]
+    g[2] = [_capsule([0, -0.06, -0.065], [0, 0.06, -0.065], 0.06)]
+    r[2] = [0, 0, -0.13]
+    g[3] = [_capsule([-0.02, -0.07, -0.10], [-0.02, 0.07, -0.10], 0.09)]
+    # ---- legs
+    thigh = 0.34 * scale_leg
+    knee_off = thigh + 0.043
+    shin = 0.30 * scale_leg
+    ankle_off = shin + 0.05
+    for side, j0 in ((-1.0, 3), (1.0, 8)):
+        r[j0] = [0, side * 0.10, -0.14]       # hip_x origin in pelvis link frame
+        g[j0 + 1] = []
+        r[j0 + 1] = [0, 0, 0]                 # hip_z co-located
+        g[j0 + 2] = []
+        r[j0 + 2] = [0, 0, 0]                 # hip_y co-located -> thigh
+        g[j0 + 3] = [_capsule([0, 0, 0], [0, 0, -thigh], 0.06)]
+        r[j0 + 3] = [0, 0, -knee_off]         # knee -> shin
+        g[j0 + 4] = [_capsule([0, 0, -0.02], [0, 0, -0.02 - shin], 0.049)]
+        r[j0 + 4] = [0, 0, -ankle_off]        # ankle -> foot
+        g[j0 + 5] = [_box([0.04, 0, -0.05], [0.10, 0.05, 0.025])]
+    # ---- arms
+    upper = 0.28 * scale_arm
+    lower = 0.25 * scale_arm
+    for side, j0 in ((-1.0, 13), (1.0, 17)):
+        r[j0] = [0, side * (torso_w + 0.10), 0.06]
+        g[j0 + 1] = []
+        r[j0 + 1] = [0, 0, 0]
+        g[j0 + 2] = []
+        r[j0 + 2] = [0, 0, 0]
+        g[j0 + 3] = [_capsule([0, 0, 0], [0, 0, -upper], 0.04)]
+        r[j0 + 3] = [0, 0, -upper]
+        g[j0 + 4] = [_capsule([0, 0, 0], [0, 0, -lower], 0.031), _sphere([0, 0, -lower - 0.02], 0.04)]
+
+    mass = np.zeros(NB)
+    com = np.zeros((NB, 3))
+    inertia_o = np.zeros((NB, 3, 3))
+    for b in range(NB):
+        m, c, Io = _compose(g[b])
+        mass[b] = m * mass_scale
+        com[b] = c
+        inertia_o[b] = Io * mass_scale
+
+    #            lo   hi          (degrees, about the +axis of the link frame)
+    rng = np.array([
+        _deg(-45, 45), _deg(-75, 30), _deg(-35, 35),
+        _deg(-25, 5), _deg(-60, 35), _deg(-110, 20), _deg(2, 160), _deg(-50, 50),
+        _deg(-5, 25), _deg(-35, 60), _deg(-110, 20), _deg(2, 160), _deg(-50, 50),
+        _deg(-120, 30), _deg(-60, 60), _deg(-120, 60), _deg(-140, -2),
+        _deg(-30, 120), _deg(-60, 60), _deg(-120, 60), _deg(-140, -2),
+    ])
+    coef = {
+        "abdomen_z": gains["abd"][0], "abdomen_y": gains["abd"][1], "abdomen_x": gains["abd"][2],
+        "hip_x": gains["hip"][0], "hip_z": gains["hip"][1], "hip_y": gains["hip"][2],
+        "knee": gains["knee"], "ankle": gains["ankle"],
+        "shoulder_x": gains["sho"][0], "shoulder_z": gains["sho"][1], "shoulder_y": gains["sho"][2],
+        "elbow": gains["elbow"],
+    }
+    damp = {"abdomen_z": 5, "abdomen_y": 5, "abdomen_x": 5, "hip_x": 5, "hip_z": 5, "hip_y": 5,
+            "knee": 1, "ankle": 1, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 1}
+    stiff = {"abdomen_z": 20, "abdomen_y": 10, "abdomen_x": 10, "hip_x": 10, "hip_z": 10, "hip_y": 20,
+             "knee": 1, "ankle": 0, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 0}
+    arm = {"abdomen_z": .02, "abdomen_y": .02, "abdomen_x": .02, "hip_x": .01, "hip_z": .01, "hip_y": .01,
+           "knee": .006, "ankle": .004, "shoulder_x": .004, "shoulder_z": .004, "shoulder_y": .004,
+           "elbow": .003}
+
+    def key(name):
+        return name.replace("right_", "").replace("left_", "")
+
+    torque = np.array([coef[key(n)] for n in JOINT_NAMES], float)
+    damping = np.array([damp[key(n)] for n in JOINT_NAMES], float)
+    stiffness = np.array([stiff[key(n)] for n in JOINT_NAMES], float)
+    armature = np.array([arm[key(n)] for n in JOINT_NAMES], float)
+    k_lim = 50.0 * torque           # unilateral limit spring  [N m / rad]
+    d_lim = 0.02 * k_lim            # limit damper (active only in violation) [N m s / rad]
+
+    # nominal pose: slight crouch so reset starts in a balanced, bent-knee stance
+    q0 = np.zeros(NJ)
+    for j0 in (3, 8):
+        q0[j0 + 2] = np.deg2rad(-12.0)   # hip_y (flexion is negative about +y)
+        q0[j0 + 3] = np.deg2rad(24.0)    # knee
+        q0[j0 + 4] = np.deg2rad(-12.0)   # ankle keeps the sole level
+    for j0 in (13, 17):
+        q0[j0 + 3] = np.deg2rad(-20.0)   # elbow inside its range
+
+    # foot sole contact points (foot link frame): 4 corners of the box bottom
+    corners = np.array([[0.14, -0.05, -0.075], [0.14, 0.05, -0.075],
+                        [-0.06, -0.05, -0.075], [-0.06, 0.05, -0.075]])
+    return dict(mass=mass, com=com, inertia_o=inertia_o, r=r, range=rng, torque=torque,
+                damping=damping, stiffness=stiffness, armature=armature, k_lim=k_lim, d_lim=d_lim,
+                q0=q0, corners=corners)
+
+
+def build(kind):
+    """kind: 'walker3d' | 'mike' -> dict of float64 numpy arrays + scalars."""
+    if kind == "walker3d":
+        m = _humanoid(1.0, 1.0, 0.07, 1.0,
+                      dict(abd=(60, 80, 60), hip=(80, 60, 100), knee=90, ankle=60,
+                           sho=(60, 60, 50), elbow=60), 0.0)
+    elif kind == "mike":
+        # Mike: stockier body, shorter limbs, stronger legs (own numbers; upstream asset absent)
+        m = _humanoid(0.85, 0.9, 0.11, 1.25,
+                      dict(abd=(80, 100, 80), hip=(100, 80, 130), knee=120, ankle=80,
+                           sho=(60, 60, 50), elbow=60), 0.04)
+    else:
+        raise ValueError("unknown robot kind %r" % (kind,))
+    m["kind"] = kind
+    m["parent"] = np.array(PARENT, np.int32)
+    m["axis"] = np.array(AXIS, np.int32)
+    m["friction"] = 0.9
+    m["stand_height"] = standing_height(m)
+    return m
+
+
+def _rot(axis, q):
+    c, s = np.cos(q), np.sin(q)
+    if axis == 0:
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == 1:
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def fk(m, q, base_pos=np.zeros(3), base_rot=np.eye(3)):
+    """World pose (R, p) of every body; numpy helper for tests and stand-height."""
+    R = [None] * NB
+    p = [None] * NB
+    R[0], p[0] = np.asarray(base_rot, float), np.asarray(base_pos, float)
+    for j in range(NJ):
+        b, par = j + 1, PARENT[j]
+        p[b] = p[par] + R[par] @ m["r"][j]
+        R[b] = R[par] @ _rot(AXIS[j], q[j])
+    return R, p
+
+
+def standing_height(m):
+    """Torso-origin height above the sole plane in the nominal pose q0."""
+    R, p = fk(m, m["q0"])
+    zmin = min((p[b] + R[b] @ c)[2] for b in (RIGHT_FOOT_BODY, LEFT_FOOT_BODY) for c in m["corners"])
+    return float(-zmin)

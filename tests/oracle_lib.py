@@ -1,0 +1,183 @@
+"""ctypes binding of the CPU oracle (oracle/ss_oracle.c).  TEST INFRASTRUCTURE: only tests/, smoke() and the
+cpu_baseline leg of bench.py may import this module; nothing under steppingstone_amd/ does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+OBS_DIM, ACT_DIM, STATE_DIM, NCELL = 60, 21, 185, 121
+KIND = {"walker3d": 0, "mike": 1}
+
+
+class Info(C.Structure):
+    _fields_ = [("ep_ret", C.c_float), ("ep_len", C.c_float), ("bad_transition", C.c_int32),
+                ("steps_reached", C.c_int32), ("update_terrain", C.c_int32)]
+
+
+INFO_DTYPE = np.dtype([("ep_ret", "f4"), ("ep_len", "f4"), ("bad_transition", "i4"), ("steps_reached", "i4"),
+                       ("update_terrain", "i4")])
+
+
+def build():
+    """(Re)build the oracle libraries with gcc if missing or stale."""
+    src = os.path.join(ORACLE_DIR, "ss_oracle.c")
+    for prec in ("f32", "f64"):
+        lib = os.path.join(ORACLE_DIR, "lib", "libss_oracle_%s.so" % prec)
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+            break
+
+
+_libs = {}
+
+
+def load(prec="f32"):
+    if prec in _libs:
+        return _libs[prec]
+    build()
+    lib = C.CDLL(os.path.join(ORACLE_DIR, "lib", "libss_oracle_%s.so" % prec))
+    vp, i32, u64, i64, dbl = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_double
+    lib.sso_create.restype = vp
+    lib.sso_create.argtypes = [i32, i32, u64, i64]
+    lib.sso_destroy.argtypes = [vp]
+    lib.sso_reset.argtypes = [vp, vp]
+    lib.sso_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sso_set_curriculum.argtypes = [vp, i32]
+    lib.sso_set_specialist.argtypes = [vp, i32]
+    lib.sso_set_sample_prob.argtypes = [vp, vp, i32]
+    lib.sso_set_power.argtypes = [vp, dbl]
+    lib.sso_create_temp_states.argtypes = [vp, vp]
+    lib.sso_get_state.argtypes = [vp, vp]
+    lib.sso_set_state.argtypes = [vp, vp]
+    lib.sso_get_obs.argtypes = [vp, vp]
+    lib.sso_random_actions.argtypes = [vp, u64, vp]
+    lib.sso_philox.argtypes = [vp, vp, vp]
+    lib.sso_debug_aba.argtypes = [i32, vp, vp, vp, vp]
+    lib.sso_debug_substeps.argtypes = [vp, i32, vp, i32, vp]
+    lib.sso_debug_fk.argtypes = [i32, vp, vp, vp]
+    _libs[prec] = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEnv:
+    """Batched oracle env with the same call surface as the C-ABI handle (numpy in/out)."""
+
+    def __init__(self, kind="walker3d", num_envs=1, seed=0, env_offset=0, prec="f32"):
+        self.lib = load(prec)
+        self.real = np.float32 if prec == "f32" else np.float64
+        self.kind = KIND[kind] if isinstance(kind, str) else int(kind)
+        self.n = int(num_envs)
+        self.h = self.lib.sso_create(self.kind, self.n, int(seed), int(env_offset))
+
+    def close(self):
+        if self.h:
+            self.lib.sso_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        obs = np.zeros((self.n, OBS_DIM), np.float32)
+        self.lib.sso_reset(self.h, _p(obs))
+        return obs
+
+    def step(self, act):
+        act = np.ascontiguousarray(act, np.float32).reshape(self.n, ACT_DIM)
+        obs = np.zeros((self.n, OBS_DIM), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        info = np.zeros(self.n, INFO_DTYPE)
+        self.lib.sso_step(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, rew, done, info
+
+    def set_curriculum(self, c):
+        self.lib.sso_set_curriculum(self.h, int(c))
+
+    def set_specialist(self, c):
+        self.lib.sso_set_specialist(self.h, int(c))
+
+    def set_sample_prob(self, p):
+        p = np.ascontiguousarray(p, np.float64)
+        per_env = 1 if p.size == self.n * NCELL and p.ndim == 3 else 0
+        assert p.size == (self.n * NCELL if per_env else NCELL)
+        self.lib.sso_set_sample_prob(self.h, _p(p), per_env)
+
+    def set_power(self, power):
+        self.lib.sso_set_power(self.h, float(power))
+
+    def create_temp_states(self):
+        out = np.zeros((self.n, NCELL, OBS_DIM), np.float32)
+        self.lib.sso_create_temp_states(self.h, _p(out))
+        return out
+
+    def get_state(self):
+        st = np.zeros((self.n, STATE_DIM), self.real)
+        self.lib.sso_get_state(self.h, _p(st))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, self.real).reshape(self.n, STATE_DIM)
+        self.lib.sso_set_state(self.h, _p(st))
+
+    def get_obs(self):
+        obs = np.zeros((self.n, OBS_DIM), np.float32)
+        self.lib.sso_get_obs(self.h, _p(obs))
+        return obs
+
+    def random_actions(self, t):
+        act = np.zeros((self.n, ACT_DIM), np.float32)
+        self.lib.sso_random_actions(self.h, int(t), _p(act))
+        return act
+
+    def substeps(self, e, tau, n):
+        tau = np.ascontiguousarray(tau, self.real)
+        flags = np.zeros(4, np.int32)
+        self.lib.sso_debug_substeps(self.h, int(e), _p(tau), int(n), _p(flags))
+        return flags
+
+
+def philox(ctr, key):
+    lib = load("f32")
+    ctr = np.asarray(ctr, np.uint32)
+    key = np.asarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib.sso_philox(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def debug_aba(kind, packed, tau, prec="f64"):
+    lib = load(prec)
+    real = np.float32 if prec == "f32" else np.float64
+    packed = np.ascontiguousarray(packed, real)
+    tau = np.ascontiguousarray(tau, real)
+    qdd = np.zeros(21, real)
+    a0 = np.zeros(6, real)
+    lib.sso_debug_aba(KIND[kind], _p(packed), _p(tau), _p(qdd), _p(a0))
+    return qdd, a0
+
+
+def debug_fk(kind, packed, prec="f64"):
+    lib = load(prec)
+    real = np.float32 if prec == "f32" else np.float64
+    packed = np.ascontiguousarray(packed, real)
+    pos = np.zeros((22, 3), real)
+    rot = np.zeros((22, 3, 3), real)
+    lib.sso_debug_fk(KIND[kind], _p(packed), _p(pos), _p(rot))
+    return pos, rot
+
+
+# packed-state slices (layout documented in include/steppingstone.h)
+S_POS, S_QUAT, S_VEL, S_Q, S_QD = slice(0, 3), slice(3, 7), slice(7, 13), slice(13, 34), slice(34, 55)
+S_POT, S_ZINIT, S_EPRET, S_NNDR, S_N, S_COUNT, S_ELAPSED, S_CTRLO, S_CTRHI, S_FLAGS = range(55, 65)
+S_TERRAIN = slice(65, 185)
