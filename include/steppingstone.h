@@ -1,0 +1,109 @@
+/*
+ * steppingstone.h -- C ABI of libsteppingstone.so: the MI355X-native vectorised stepping-stone environment.
+ *
+ * The reference has no FFI for this path: its boundary is the Python object protocol between
+ * common/envs_utils.py (ShmemVecEnv / _subproc_worker) and the gym env in the un-vendored mocca_envs submodule.
+ * Every entry point below therefore cites the reference call site(s) whose job it takes over.  A reference
+ * maintainer binds these with ctypes (INTEGRATION.md shows the stub); no torch types cross this boundary.
+ *
+ * Conventions: all functions return 0 on success or a negative ss_status; ss_last_error() returns a thread-local
+ * message.  The caller owns every I/O buffer (device pointers, e.g. tensor.data_ptr()); the library owns the
+ * structure-of-arrays environment state in HBM.  All device work is ordered on the hipStream_t passed in (as
+ * void*; NULL = the null stream) and nothing synchronises the host.  One handle per (process, device); a
+ * handle is not thread-safe.
+ */
+#ifndef STEPPINGSTONE_H
+#define STEPPINGSTONE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OBS_DIM 60     /* shipped checkpoints: actor.state_dim */
+#define SS_ACT_DIM 21     /* common/render_utils.py:47-69 */
+#define SS_GRID 11        /* playground/train.py:132-133 (11x11 yaw x pitch grid, centre index 5) */
+#define SS_NCELL 121
+#define SS_NUM_STONES 20
+#define SS_STATE_DIM 185  /* packed per-env state of ss_get_state / ss_set_state */
+#define SS_MAX_EPISODE_STEPS 1000
+
+typedef enum { SS_WALKER3D = 0, SS_MIKE = 1 } ss_kind;   /* ids: README.md:27,31 of the reference */
+
+typedef enum {
+  SS_OK = 0,
+  SS_ERR_INVALID = -1,   /* bad argument */
+  SS_ERR_HIP = -2,       /* a HIP runtime call failed (message has hipGetErrorString) */
+  SS_ERR_NO_DEVICE = -3, /* no gfx950 device visible: there is NO CPU fallback */
+  SS_ERR_ALLOC = -4
+} ss_status;
+
+/* per-env step report; replaces the `info` dict built by Monitor.update (common/envs_utils.py:131-153) and
+ * TimeLimitMask.step (:59-65) plus env.update_terrain (playground/train.py:245). ep_* valid when done. */
+typedef struct {
+  float ep_ret;            /* info["episode"]["r"] */
+  float ep_len;            /* info["episode"]["l"] */
+  int32_t bad_transition;  /* info["bad_transition"] */
+  int32_t steps_reached;   /* next_step_index at the end of the step */
+  int32_t update_terrain;  /* env.update_terrain */
+} ss_info;
+
+typedef struct ss_env ss_env;
+
+/* gym.make(env_id) + env.seed(seed + rank) for num_envs envs at once (common/envs_utils.py:25-40,48-56).
+ * env_id_offset: global index of this handle's first env (multi-GPU sharding keeps RNG streams rank-invariant). */
+int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t seed, int64_t env_id_offset);
+void ss_destroy(ss_env* env);                                   /* env.close(), envs_utils.py:667-676 */
+const char* ss_last_error(void);
+
+/* ShmemVecEnv.reset (envs_utils.py:542-548): obs [num_envs, 60] f32 row-major, device pointer. */
+int ss_reset(ss_env* env, float* obs, void* stream);
+
+/* ShmemVecEnv.step_async + step_wait + worker auto-reset (envs_utils.py:550-558, 646-649).
+ * act [N,21] f32; obs [N,60] f32; rew [N] f32; done [N] u8; info [N] ss_info (may be NULL).  Device pointers. */
+int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream);
+
+/* Benchmark path (BASELINE.json metric "batched random-action rollout"): K steps with on-device Philox
+ * actions U(-1,1), one kernel launch per step; t0 = index of the first step in the action stream. */
+int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, float* rew, uint8_t* done,
+                      ss_info* info, void* stream);
+/* Same action stream written to act [N,21] (parity tests / external policies). */
+int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream);
+
+/* Curriculum hooks (envs_utils.py:568-590, 650-664; playground/train.py:118,122,271). */
+int ss_set_curriculum(ss_env* env, int32_t level);              /* env.update_curriculum */
+int ss_set_specialist(ss_env* env, int32_t level);              /* env.update_specialist */
+/* env.update_sample_prob: HOST pointer to f64 probabilities, [N,11,11] if per_env else [11,11]. */
+int ss_set_sample_prob(ss_env* env, const double* prob, int per_env);
+int ss_set_mirror(ss_env* env, int32_t on);                     /* env.set_mirror (train.py:109) */
+int ss_set_power(ss_env* env, float power);                     /* env.set_robot_params({"power": p}) */
+/* on (default): worker semantics, a finished env is reset inside the step (envs_utils.py:647-648);
+ * off: plain gym env semantics for make_env() users -- terminal obs returned, caller resets (train.py:243-244). */
+int ss_set_auto_reset(ss_env* env, int32_t on);
+
+/* env.create_temp_states (train.py:247, envs_utils.py:573-578): out [N,121,60] f32, device pointer. */
+int ss_create_temp_states(ss_env* env, float* out, void* stream);
+
+/* env.unwrapped.get_mirror_indices() (train.py:160; consumed by get_mirror_function, envs_utils.py:687-694).
+ * buf receives the 6 index lists back to back, lens[6] their lengths; buf must hold 2*(60+21) int32. */
+int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens);
+
+/* Full-state injection / extraction for parity tests and terrain_info (enjoy.py:60-64).  DEVICE pointers,
+ * [N, SS_STATE_DIM] f32 row-major:
+ *   0:3 pos | 3:7 quat wxyz | 7:13 base twist (body frame, angular first) | 13:34 q | 34:55 qd |
+ *   55 pot_prev | 56 z_init | 57 ep_ret | 58 next-next dr | 59 next_step_index | 60 target_reached_count |
+ *   61 elapsed | 62 rng_ctr & 0xffff | 63 rng_ctr >> 16 | 64 flags (bit0 right, bit1 left foot contact) |
+ *   65:185 terrain_info [20][6] = x,y,z,phi,x_tilt,y_tilt */
+int ss_get_state(ss_env* env, float* packed, void* stream);
+int ss_set_state(ss_env* env, const float* packed, void* stream);
+/* Observation of the current state without stepping (used after ss_set_state). */
+int ss_get_obs(ss_env* env, float* obs, void* stream);
+
+int32_t ss_num_envs(const ss_env* env);
+int ss_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -197,7 +197,7 @@ typedef struct {
 } sso_info;
 
 typedef struct {
-  int kind, num_envs, curriculum;
+  int kind, num_envs, curriculum, auto_reset;
   uint64_t seed;
   int64_t env_offset;
   real power;
@@ -578,12 +578,9 @@ static void write_obs(const sso_model* M, const env_state* s, float* o) {
 static void env_reset(const sso_env* E, int e) {
   const sso_model* M = E->M;
   env_state* s = &E->e[e];
+  /* provisional straight, flat path; stone k >= 3 is drawn when it becomes the look-ahead stone (PHYSICS.md 6) */
   memset(s->terrain, 0, sizeof s->terrain);
-  s->terrain[1][0] = (real)0.75;
-  s->terrain[2][0] = (real)1.5;
-  for (int k = 3; k < NSTONE; ++k) {
-    (void)draw_stone(E, e, s, k);
-  }
+  for (int k = 1; k < NSTONE; ++k) s->terrain[k][0] = (real)0.75 * (real)k;
   s->n = 1; s->count = 0; s->elapsed = 0; s->flags = 0;
   s->nn_dr = (real)0.75;
   s->pos[0] = 0; s->pos[1] = 0; s->pos[2] = M->stand_height + (real)0.01;
@@ -683,7 +680,7 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   info->bad_transition = bad;
   info->steps_reached = s->n;
   info->update_terrain = advanced;
-  if (d) env_reset(E, e);
+  if (d && E->auto_reset) env_reset(E, e);
   write_obs(M, s, obs);
 }
 
@@ -703,7 +700,7 @@ static void fill_window(float* prob, int c, int ring) {
 sso_env* sso_create(int kind, int num_envs, uint64_t seed, int64_t env_offset) {
   sso_env* E = (sso_env*)calloc(1, sizeof *E);
   E->kind = kind; E->num_envs = num_envs; E->seed = seed; E->env_offset = env_offset;
-  E->M = &SSO_MODELS[kind]; E->power = 1; E->curriculum = 0;
+  E->M = &SSO_MODELS[kind]; E->power = 1; E->curriculum = 0; E->auto_reset = 1;
   E->e = (env_state*)calloc((size_t)num_envs, sizeof(env_state));
   for (int e = 0; e < num_envs; ++e) { fill_window(E->e[e].prob, 0, 0); E->e[e].quat[0] = 1; }
   return E;
@@ -730,6 +727,7 @@ void sso_set_sample_prob(sso_env* E, const double* p, int per_env) {
     for (int k = 0; k < NCELL; ++k) E->e[e].prob[k] = (float)p[per_env ? (size_t)e * NCELL + (size_t)k : (size_t)k];
 }
 void sso_set_power(sso_env* E, double power) { E->power = (real)power; }
+void sso_set_auto_reset(sso_env* E, int on) { E->auto_reset = on ? 1 : 0; }
 void sso_create_temp_states(sso_env* E, float* out) {
   for (int e = 0; e < E->num_envs; ++e) {
     env_state tmp = E->e[e];

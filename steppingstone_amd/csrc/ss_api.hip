@@ -1,0 +1,283 @@
+// ss_api.hip -- C ABI of libsteppingstone.so (include/steppingstone.h).  Host side only: owns the HBM-resident
+// structure-of-arrays state and launches the gfx950 kernels on the caller's stream.  There is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ss_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define SS_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (call);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(SS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                      \
+  } while (0)
+
+}  // namespace
+
+struct ss_env {
+  ss::Params P;
+  int kind;
+  int device;
+  float* prob_shared;   // [121]
+  float* prob_env;      // [121][npad] or null
+};
+
+namespace {
+
+void window_prob(float* p, int c, bool ring) {
+  int cnt = 0;
+  for (int i = 0; i < SS_GRID; ++i)
+    for (int j = 0; j < SS_GRID; ++j) {
+      int di = std::abs(i - 5), dj = std::abs(j - 5), m = di > dj ? di : dj;
+      bool in = ring ? (m == c) : (m <= c);
+      p[i * SS_GRID + j] = in ? 1.f : 0.f;
+      cnt += in;
+    }
+  for (int k = 0; k < SS_NCELL; ++k) p[k] = p[k] / (float)cnt;
+}
+
+int set_window(ss_env* env, int level, bool ring) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (level < 0 || level > 5) return fail(SS_ERR_INVALID, "curriculum level must be in 0..5");
+  float p[SS_NCELL];
+  window_prob(p, level, ring);
+  SS_HIP(hipSetDevice(env->device));
+  SS_HIP(hipMemcpy(env->prob_shared, p, sizeof p, hipMemcpyHostToDevice));
+  env->P.curriculum = level;
+  env->P.prob = env->prob_shared;
+  env->P.per_env_prob = 0;
+  return SS_OK;
+}
+
+inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
+
+template <bool RANDOM>
+int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
+  if (env->kind == SS_WALKER3D)
+    hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid64(env), dim3(ss::kWave), 0, st, env->P, io);
+  else
+    hipLaunchKernelGGL((ss::step_kernel<ss::ModelMike, RANDOM>), grid64(env), dim3(ss::kWave), 0, st, env->P, io);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ss_last_error(void) { return g_err.c_str(); }
+int ss_version(void) { return 1; }
+int32_t ss_num_envs(const ss_env* env) { return env ? env->P.n : 0; }
+
+int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t seed, int64_t env_id_offset) {
+  if (!out) return fail(SS_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (kind != SS_WALKER3D && kind != SS_MIKE) return fail(SS_ERR_INVALID, "unknown robot kind");
+  if (num_envs <= 0) return fail(SS_ERR_INVALID, "num_envs must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SS_ERR_NO_DEVICE, "no HIP device visible: libsteppingstone has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SS_ERR_INVALID, "device index out of range");
+  SS_HIP(hipSetDevice(device));
+  ss_env* env = new ss_env();
+  std::memset(env, 0, sizeof *env);
+  env->kind = kind;
+  env->device = device;
+  ss::Params& P = env->P;
+  P.n = num_envs;
+  P.npad = (num_envs + ss::kWave - 1) / ss::kWave * ss::kWave;
+  P.seed_lo = (uint32_t)seed;
+  P.seed_hi = (uint32_t)(seed >> 32);
+  P.env_offset = (uint32_t)env_id_offset;
+  P.curriculum = 0;
+  P.power = 1.0f;
+  P.auto_reset = 1;
+  const size_t np = (size_t)P.npad;
+  hipError_t e1 = hipMalloc(&P.fstate, sizeof(float) * ss::NF * np);
+  hipError_t e2 = hipMalloc(&P.istate, sizeof(int) * ss::NI * np);
+  hipError_t e3 = hipMalloc(&P.terrain, sizeof(float) * 120 * np);
+  hipError_t e4 = hipMalloc(&env->prob_shared, sizeof(float) * SS_NCELL);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    ss_destroy(env);
+    return fail(SS_ERR_ALLOC, "hipMalloc failed for the environment state");
+  }
+  SS_HIP(hipMemset(P.fstate, 0, sizeof(float) * ss::NF * np));
+  SS_HIP(hipMemset(P.istate, 0, sizeof(int) * ss::NI * np));
+  SS_HIP(hipMemset(P.terrain, 0, sizeof(float) * 120 * np));
+  int rc = set_window(env, 0, false);
+  if (rc != SS_OK) { ss_destroy(env); return rc; }
+  *out = env;
+  return SS_OK;
+}
+
+void ss_destroy(ss_env* env) {
+  if (!env) return;
+  (void)hipSetDevice(env->device);
+  if (env->P.fstate) (void)hipFree(env->P.fstate);
+  if (env->P.istate) (void)hipFree(env->P.istate);
+  if (env->P.terrain) (void)hipFree(env->P.terrain);
+  if (env->prob_shared) (void)hipFree(env->prob_shared);
+  if (env->prob_env) (void)hipFree(env->prob_env);
+  delete env;
+}
+
+int ss_reset(ss_env* env, float* obs, void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  hipStream_t st = (hipStream_t)stream;
+  if (env->kind == SS_WALKER3D)
+    hipLaunchKernelGGL((ss::reset_kernel<ss::ModelWalker3D>), grid64(env), dim3(ss::kWave), 0, st, env->P, obs);
+  else
+    hipLaunchKernelGGL((ss::reset_kernel<ss::ModelMike>), grid64(env), dim3(ss::kWave), 0, st, env->P, obs);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (!act || !obs || !rew || !done) return fail(SS_ERR_INVALID, "act/obs/rew/done must be device pointers");
+  ss::StepIO io{act, obs, rew, done, info, 0};
+  return launch_step<false>(env, io, (hipStream_t)stream);
+}
+
+int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, float* rew, uint8_t* done,
+                      ss_info* info, void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (!obs || !rew || !done) return fail(SS_ERR_INVALID, "obs/rew/done must be device pointers");
+  for (int32_t k = 0; k < num_steps; ++k) {
+    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k};
+    int rc = launch_step<true>(env, io, (hipStream_t)stream);
+    if (rc != SS_OK) return rc;
+  }
+  return SS_OK;
+}
+
+int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream) {
+  if (!env || !act) return fail(SS_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(ss::random_actions_kernel, dim3((env->P.n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     env->P, t, act);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_set_curriculum(ss_env* env, int32_t level) { return set_window(env, level, false); }
+int ss_set_specialist(ss_env* env, int32_t level) { return set_window(env, level, true); }
+
+int ss_set_sample_prob(ss_env* env, const double* prob, int per_env) {
+  if (!env || !prob) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
+  if (!per_env) {
+    float p[SS_NCELL];
+    for (int k = 0; k < SS_NCELL; ++k) p[k] = (float)prob[k];
+    SS_HIP(hipMemcpy(env->prob_shared, p, sizeof p, hipMemcpyHostToDevice));
+    env->P.prob = env->prob_shared;
+    env->P.per_env_prob = 0;
+    return SS_OK;
+  }
+  const size_t np = (size_t)env->P.npad;
+  if (!env->prob_env) SS_HIP(hipMalloc(&env->prob_env, sizeof(float) * SS_NCELL * np));
+  std::vector<float> t(SS_NCELL * np, 0.f);
+  for (int e = 0; e < env->P.n; ++e)
+    for (int k = 0; k < SS_NCELL; ++k) t[(size_t)k * np + e] = (float)prob[(size_t)e * SS_NCELL + k];
+  SS_HIP(hipMemcpy(env->prob_env, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+  env->P.prob = env->prob_env;
+  env->P.per_env_prob = 1;
+  return SS_OK;
+}
+
+int ss_set_mirror(ss_env* env, int32_t on) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  (void)on;   // phase mirroring is a no-op for the (phase-free) Walker3D/Mike steppers
+  return SS_OK;
+}
+
+int ss_set_power(ss_env* env, float power) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  env->P.power = power;
+  return SS_OK;
+}
+
+int ss_set_auto_reset(ss_env* env, int32_t on) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  env->P.auto_reset = on ? 1 : 0;
+  return SS_OK;
+}
+
+int ss_create_temp_states(ss_env* env, float* out, void* stream) {
+  if (!env || !out) return fail(SS_ERR_INVALID, "null argument");
+  const int total = env->P.n * SS_NCELL;
+  dim3 grid((total + 255) / 256), block(256);
+  if (env->kind == SS_WALKER3D)
+    hipLaunchKernelGGL((ss::temp_states_kernel<ss::ModelWalker3D>), grid, block, 0, (hipStream_t)stream, env->P, out);
+  else
+    hipLaunchKernelGGL((ss::temp_states_kernel<ss::ModelMike>), grid, block, 0, (hipStream_t)stream, env->P, out);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens) {
+  if (!buf || !lens) return fail(SS_ERR_INVALID, "null argument");
+  (void)kind;   // both robots share the topology
+  static const int neg_j[] = {0, 2, 3, 4, 8, 9, 13, 14, 17, 18};
+  static const int right_j[] = {3, 4, 5, 6, 7, 13, 14, 15, 16};
+  static const int left_j[] = {8, 9, 10, 11, 12, 17, 18, 19, 20};
+  std::vector<int32_t> neg_obs = {2, 4}, right_obs, left_obs, neg_act, right_act, left_act;
+  for (int j : neg_j) neg_obs.push_back(6 + j);
+  for (int j : neg_j) neg_obs.push_back(27 + j);
+  for (int i : {50, 53, 55, 58}) neg_obs.push_back(i);
+  for (int j : right_j) right_obs.push_back(6 + j);
+  for (int j : right_j) right_obs.push_back(27 + j);
+  right_obs.push_back(48);
+  for (int j : left_j) left_obs.push_back(6 + j);
+  for (int j : left_j) left_obs.push_back(27 + j);
+  left_obs.push_back(49);
+  for (int j : neg_j) neg_act.push_back(j);
+  for (int j : right_j) right_act.push_back(j);
+  for (int j : left_j) left_act.push_back(j);
+  const std::vector<int32_t>* lists[6] = {&neg_obs, &right_obs, &left_obs, &neg_act, &right_act, &left_act};
+  int32_t* o = buf;
+  for (int i = 0; i < 6; ++i) {
+    lens[i] = (int32_t)lists[i]->size();
+    for (int32_t v : *lists[i]) *o++ = v;
+  }
+  return SS_OK;
+}
+
+int ss_get_state(ss_env* env, float* packed, void* stream) {
+  if (!env || !packed) return fail(SS_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(ss::pack_state_kernel, dim3((env->P.n + 63) / 64), dim3(64), 0, (hipStream_t)stream, env->P, packed);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_set_state(ss_env* env, const float* packed, void* stream) {
+  if (!env || !packed) return fail(SS_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(ss::unpack_state_kernel, dim3((env->P.n + 63) / 64), dim3(64), 0, (hipStream_t)stream, env->P, packed);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_get_obs(ss_env* env, float* obs, void* stream) {
+  if (!env || !obs) return fail(SS_ERR_INVALID, "null argument");
+  if (env->kind == SS_WALKER3D)
+    hipLaunchKernelGGL((ss::obs_kernel<ss::ModelWalker3D>), grid64(env), dim3(ss::kWave), 0, (hipStream_t)stream, env->P, obs);
+  else
+    hipLaunchKernelGGL((ss::obs_kernel<ss::ModelMike>), grid64(env), dim3(ss::kWave), 0, (hipStream_t)stream, env->P, obs);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+}  // extern "C"

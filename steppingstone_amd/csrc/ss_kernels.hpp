@@ -1,0 +1,564 @@
+// ss_kernels.hpp -- environment logic around the physics substep: control step, reward, termination,
+// auto-reset, terrain sampler, observation assembly (docs/PHYSICS.md sections 4-8).
+//
+// HBM layout (structure of arrays, env index fastest so every field access of a wavefront is one coalesced
+// 256-byte transaction):
+//   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8
+//   istate [NI][Npad] int   : next_step_index, target_reached_count, elapsed, rng_ctr, flags
+//   terrain [20*6][Npad] float : terrain_info (touched only on reset / stone advance / get_state)
+//   prob   [121] float shared grid, or [121][Npad] per-env grids
+#pragma once
+#include "ss_dynamics.hpp"
+#include "../../include/steppingstone.h"
+
+namespace ss {
+
+enum { F_POS = 0, F_QUAT = 3, F_VEL = 7, F_Q = 13, F_QD = 34, F_POT = 55, F_ZINIT = 56, F_EPRET = 57, F_NNDR = 58,
+       F_STONE = 59, NF = 59 + 24 };
+enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, NI = 5 };
+constexpr int kNumStones = 20;
+constexpr float kDeg = 0.017453292519943295f;
+
+struct Params {
+  float* fstate;
+  int* istate;
+  float* terrain;
+  const float* prob;     // shared [121] or per-env [121][Npad]
+  int per_env_prob;
+  int n;                 // number of envs
+  int npad;              // padded to a multiple of 64
+  uint32_t seed_lo, seed_hi;
+  uint32_t env_offset;
+  int curriculum;
+  float power;
+  int auto_reset;
+};
+
+struct Cache {           // active stones n-1, n, n+1: centre, normal, tilts
+  float p[3][3], nrm[3][3], tilt[3][2];
+};
+
+SSD float yaw_sample(int i) { return (-20.0f + 4.0f * (float)i) * kDeg; }
+SSD float pitch_sample(int j) { return (-30.0f + 6.0f * (float)j) * kDeg; }
+
+SSD void stone_normal(float phi, float xt, float yt, float n[3]) {
+  float sx, cx, sy, cy, sp, cp;
+  sincosf(xt, &sx, &cx);
+  sincosf(yt, &sy, &cy);
+  sincosf(phi, &sp, &cp);
+  float x1 = sy * cx, y1 = -sx, z1 = cy * cx;
+  n[0] = cp * x1 - sp * y1;
+  n[1] = sp * x1 + cp * y1;
+  n[2] = z1;
+}
+
+SSD void env_block(const Params& P, int e, uint32_t& ctr, uint32_t out[4]) {
+  philox4x32_10(ctr, 0u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, out);
+  ctr += 1u;
+}
+
+SSD int sample_cell(const Params& P, int e, float u) {
+  float cdf = 0.f;
+  int last = 0, pick = -1;
+  const float* pr = P.per_env_prob ? P.prob + e : P.prob;
+  const int stride = P.per_env_prob ? P.npad : 1;
+#pragma unroll 1
+  for (int k = 0; k < SS_NCELL; ++k) {
+    float pk = pr[(size_t)k * stride];
+    if (pk > 0.f) last = k;
+    cdf += pk;
+    if (pick < 0 && u < cdf) pick = k;
+  }
+  return pick < 0 ? last : pick;
+}
+
+// draw stone k from stone k-1 (terrain table), write it to the table; returns dr and the new stone's data
+SSD float draw_stone(const Params& P, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3], float out_t[2]) {
+  uint32_t r[4];
+  env_block(P, e, ctr, r);
+  int cell = sample_cell(P, e, u01(r[0]));
+  float ratio = (float)P.curriculum / 5.0f;
+  float dr = 0.65f + u01(r[1]) * (0.6f * ratio);
+  float tilt = 15.0f * kDeg * ratio;
+  float xt = (2.f * u01(r[2]) - 1.f) * tilt, yt = (2.f * u01(r[3]) - 1.f) * tilt;
+  float yaw = yaw_sample(cell / SS_GRID), pitch = pitch_sample(cell % SS_GRID);
+  const size_t np = (size_t)P.npad;
+  float* T = P.terrain + e;
+  float px = T[((k - 1) * 6 + 0) * np], py = T[((k - 1) * 6 + 1) * np], pz = T[((k - 1) * 6 + 2) * np];
+  float phi = T[((k - 1) * 6 + 3) * np] + yaw;
+  float sp, cp, sph, cph;
+  sincosf(pitch, &sp, &cp);
+  sincosf(phi, &sph, &cph);
+  float planar = dr * cp;
+  out_p[0] = px + planar * cph;
+  out_p[1] = py + planar * sph;
+  out_p[2] = pz + dr * sp;
+  out_t[0] = xt; out_t[1] = yt;
+  stone_normal(phi, xt, yt, out_n);
+  T[(k * 6 + 0) * np] = out_p[0]; T[(k * 6 + 1) * np] = out_p[1]; T[(k * 6 + 2) * np] = out_p[2];
+  T[(k * 6 + 3) * np] = phi; T[(k * 6 + 4) * np] = xt; T[(k * 6 + 5) * np] = yt;
+  return dr;
+}
+
+SSD void quat_rpy(const float q[4], float& roll, float& pitch, float& yaw) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  roll = atan2f(2.f * (w * x + y * z), 1.f - 2.f * (x * x + y * y));
+  pitch = asinf(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
+  yaw = atan2f(2.f * (w * z + x * y), 1.f - 2.f * (y * y + z * z));
+}
+
+SSD float planar_dist(const float a[3], const float b[3]) {
+  float dx = a[0] - b[0], dy = a[1] - b[1];
+  return sqrtf(dx * dx + dy * dy);
+}
+
+SSD void target_features(const float pos[3], float yaw, const float sp[3], const float tilt[2], float o[5]) {
+  float dx = sp[0] - pos[0], dy = sp[1] - pos[1], dz = sp[2] - pos[2];
+  float d = sqrtf(dx * dx + dy * dy), ang = atan2f(dy, dx) - yaw;
+  float sa, ca;
+  sincosf(ang, &sa, &ca);
+  o[0] = sa * d; o[1] = ca * d; o[2] = dz; o[3] = tilt[0]; o[4] = tilt[1];
+}
+
+SSD float clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
+
+// observation (PHYSICS.md section 5) written row-major to obs[60]
+template <class Model>
+SSD void write_obs(const Dyn& s, float z_init, int flags, const Cache& c, float* obs) {
+  float roll, pitch, yaw;
+  quat_rpy(s.quat, roll, pitch, yaw);
+  float R[3][3];
+  quat_rot(s.quat, R);
+  float vw[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) vw[r] = R[r][0] * s.v0.v[0] + R[r][1] * s.v0.v[1] + R[r][2] * s.v0.v[2];
+  float sy, cy;
+  sincosf(yaw, &sy, &cy);
+  obs[0] = clip5(s.pos[2] - z_init);
+  obs[1] = clip5(cy * vw[0] + sy * vw[1]);
+  obs[2] = clip5(-sy * vw[0] + cy * vw[1]);
+  obs[3] = clip5(vw[2]);
+  obs[4] = clip5(roll);
+  obs[5] = clip5(pitch);
+  static_for<0, NJ>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+    constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
+    constexpr float span = Model::hi[j] - Model::lo[j];
+    obs[6 + j] = clip5(2.f * (s.q[j] - mid) / span);
+    obs[27 + j] = clip5(0.1f * s.qd[j]);
+  });
+  obs[48] = (flags & 1) ? 1.f : 0.f;
+  obs[49] = (flags & 2) ? 1.f : 0.f;
+  float t[5];
+  target_features(s.pos, yaw, c.p[1], c.tilt[1], t);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) obs[50 + i] = t[i];
+  target_features(s.pos, yaw, c.p[2], c.tilt[2], t);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) obs[55 + i] = t[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+SSD void load_dyn(const Params& P, int e, Dyn& s) {
+  const float* F = P.fstate + e;
+  const size_t np = (size_t)P.npad;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s.pos[i] = F[(F_POS + i) * np];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s.quat[i] = F[(F_QUAT + i) * np];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { s.v0.w[i] = F[(F_VEL + i) * np]; s.v0.v[i] = F[(F_VEL + 3 + i) * np]; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { s.q[j] = F[(F_Q + j) * np]; s.qd[j] = F[(F_QD + j) * np]; }
+}
+SSD void store_dyn(const Params& P, int e, const Dyn& s) {
+  float* F = P.fstate + e;
+  const size_t np = (size_t)P.npad;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) F[(F_POS + i) * np] = s.pos[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) F[(F_QUAT + i) * np] = s.quat[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { F[(F_VEL + i) * np] = s.v0.w[i]; F[(F_VEL + 3 + i) * np] = s.v0.v[i]; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { F[(F_Q + j) * np] = s.q[j]; F[(F_QD + j) * np] = s.qd[j]; }
+}
+SSD void load_cache(const Params& P, int e, Cache& c) {
+  const float* F = P.fstate + e;
+  const size_t np = (size_t)P.npad;
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c.p[sl][i] = F[(F_STONE + sl * 8 + i) * np]; c.nrm[sl][i] = F[(F_STONE + sl * 8 + 3 + i) * np]; }
+    c.tilt[sl][0] = F[(F_STONE + sl * 8 + 6) * np];
+    c.tilt[sl][1] = F[(F_STONE + sl * 8 + 7) * np];
+  }
+}
+SSD void store_cache(const Params& P, int e, const Cache& c) {
+  float* F = P.fstate + e;
+  const size_t np = (size_t)P.npad;
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { F[(F_STONE + sl * 8 + i) * np] = c.p[sl][i]; F[(F_STONE + sl * 8 + 3 + i) * np] = c.nrm[sl][i]; }
+    F[(F_STONE + sl * 8 + 6) * np] = c.tilt[sl][0];
+    F[(F_STONE + sl * 8 + 7) * np] = c.tilt[sl][1];
+  }
+}
+// rebuild the active-stone cache of env e from the terrain table (after set_state)
+SSD void cache_from_terrain(const Params& P, int e, int n, Cache& c) {
+  const size_t np = (size_t)P.npad;
+  const float* T = P.terrain + e;
+  int idx[3] = {n - 1 < 0 ? 0 : n - 1, n, n + 1 > kNumStones - 1 ? kNumStones - 1 : n + 1};
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    int k = idx[sl];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.p[sl][i] = T[(k * 6 + i) * np];
+    float phi = T[(k * 6 + 3) * np], xt = T[(k * 6 + 4) * np], yt = T[(k * 6 + 5) * np];
+    c.tilt[sl][0] = xt; c.tilt[sl][1] = yt;
+    stone_normal(phi, xt, yt, c.nrm[sl]);
+  }
+}
+
+// PHYSICS.md section 7
+template <class Model>
+SSD void env_reset(const Params& P, int e, Dyn& s, Cache& c, uint32_t& ctr, float& pot, float& z_init, float& nn_dr) {
+  const size_t np = (size_t)P.npad;
+  float* T = P.terrain + e;
+#pragma unroll 1
+  for (int k = 0; k < kNumStones; ++k) {
+    T[(k * 6 + 0) * np] = 0.75f * (float)k;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) T[(k * 6 + i) * np] = 0.f;
+  }
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
+    c.nrm[sl][0] = 0.f; c.nrm[sl][1] = 0.f; c.nrm[sl][2] = 1.f;
+    c.tilt[sl][0] = 0.f; c.tilt[sl][1] = 0.f;
+  }
+  s.pos[0] = 0.f; s.pos[1] = 0.f; s.pos[2] = Model::stand_height + 0.01f;
+  s.quat[0] = 1.f; s.quat[1] = s.quat[2] = s.quat[3] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { s.v0.w[i] = 0.f; s.v0.v[i] = 0.f; }
+  uint32_t r[6][4];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) env_block(P, e, ctr, r[b]);
+  static_for<0, NJ>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+    constexpr float q0 = Model::q0[j], lo = Model::lo[j] + 0.02f, hi = Model::hi[j] - 0.02f;
+    float q = q0 + 0.05f * (2.f * u01(r[j / 4][j % 4]) - 1.f);
+    s.q[j] = fminf(fmaxf(q, lo), hi);
+    s.qd[j] = 0.f;
+  });
+  z_init = s.pos[2];
+  nn_dr = 0.75f;
+  pot = -planar_dist(c.p[1], s.pos) / kDt;
+}
+
+struct StepIO {
+  const float* act;   // [N,21] or null when actions are generated on device
+  float* obs;         // [N,60]
+  float* rew;         // [N]
+  uint8_t* done;      // [N]
+  ss_info* info;      // [N] or null
+  uint64_t t;         // action-stream index for RANDOM_ACT
+};
+
+// one control step of env e_raw (lane-private LDS column `lane` of lds4); PHYSICS.md section 4
+template <class Model, bool RANDOM_ACT>
+SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4* lds4) {
+  const bool valid = e_raw < P.n;
+  const int e = valid ? e_raw : P.n - 1;
+  const size_t np = (size_t)P.npad;
+
+  Dyn s;
+  Cache c;
+  load_dyn(P, e, s);
+  load_cache(P, e, c);
+  float pot_prev = P.fstate[e + F_POT * np], z_init = P.fstate[e + F_ZINIT * np];
+  float ep_ret = P.fstate[e + F_EPRET * np], nn_dr = P.fstate[e + F_NNDR * np];
+  int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
+  uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
+
+  // 1. action -> motor torques
+  float a[NJ], tau[NJ];
+  if constexpr (RANDOM_ACT) {
+    uint32_t r[6][4];
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r[b]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a[j] = 2.f * u01(r[j / 4][j % 4]) - 1.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) a[j] = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
+  }
+  static_for<0, NJ>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+    tau[j] = P.power * Model::torque[j] * a[j];
+  });
+
+  // 2. four substeps
+  Stones st;
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st.p[sl][i] = c.p[sl][i]; st.n[sl][i] = c.nrm[sl][i]; }
+  FootReport fr;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) substep<Model>(s, tau, st, fr, lds4, lane);
+
+  // 3-4
+  elapsed += 1;
+  int flags = fr.contact;
+  bool finite = true;
+  {
+    float accv = s.pos[0] + s.pos[1] + s.pos[2] + s.quat[0] + s.quat[1] + s.quat[2] + s.quat[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) accv += s.v0.w[i] + s.v0.v[i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) accv += s.q[j] + s.qd[j];
+    finite = finite_bits(accv);
+  }
+  // 5. target logic
+  float target_old[3] = {c.p[1][0], c.p[1][1], c.p[1][2]};
+  float step_bonus = 0.f;
+  int advanced = 0;
+  if (fr.on_target != 0) {
+    count += 1;
+    if (count == 1) {
+      float d0 = planar_dist(fr.sole[0], target_old), d1 = planar_dist(fr.sole[1], target_old);
+      step_bonus = 50.f * expf(-fminf(d0, d1) / 0.25f);
+    }
+    if (count >= 2 && n < kNumStones - 1) {
+      n += 1;
+      count = 0;
+      advanced = 1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        c.p[0][i] = c.p[1][i]; c.nrm[0][i] = c.nrm[1][i];
+        c.p[1][i] = c.p[2][i]; c.nrm[1][i] = c.nrm[2][i];
+      }
+      c.tilt[0][0] = c.tilt[1][0]; c.tilt[0][1] = c.tilt[1][1];
+      c.tilt[1][0] = c.tilt[2][0]; c.tilt[1][1] = c.tilt[2][1];
+      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2]);
+    }
+  }
+  // 6. progress
+  float pot = -planar_dist(target_old, s.pos) / kDt;
+  float progress = pot - pot_prev;
+  pot_prev = advanced ? -planar_dist(c.p[1], s.pos) / kDt : pot;
+  // 7-8
+  float target_bonus = (n == kNumStones - 1 && planar_dist(c.p[1], s.pos) < 0.15f) ? 2.f : 0.f;
+  float zs = fminf(fr.sole[0][2], fr.sole[1][2]);
+  float tall_bonus = (s.pos[2] - zs > 0.7f) ? 2.f : -1.f;
+  float zlow = fminf(fminf(c.p[0][2], c.p[1][2]), c.p[2][2]);
+  bool d = (tall_bonus < 0.f) || (s.pos[2] < zlow + 0.3f) || !finite;
+  bool timeout = elapsed >= SS_MAX_EPISODE_STEPS;
+  int bad = (timeout && !d) ? 1 : 0;
+  d = d || timeout;
+  // 9. reward
+  float roll, pitch, yaw;
+  quat_rpy(s.quat, roll, pitch, yaw);
+  float posture = 0.f;
+  if (!(pitch > -0.2f && pitch < 0.4f)) posture += fabsf(pitch);
+  if (!(roll > -0.4f && roll < 0.4f)) posture += fabsf(roll);
+  float e_sum = 0.f, a2 = 0.f;
+  int at_limit = 0;
+  static_for<0, NJ>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+    constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
+    constexpr float span = Model::hi[j] - Model::lo[j];
+    e_sum += fabsf(a[j] * (0.1f * s.qd[j]));
+    a2 += a[j] * a[j];
+    if (fabsf(2.f * (s.q[j] - mid) / span) > 0.99f) at_limit += 1;
+  });
+  float energy = (4.5f / NJ) * (e_sum / NJ) + (0.225f / NJ) * (a2 / NJ);
+  float r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - 0.1f * (float)at_limit;
+  if (!finite || !finite_bits(r)) r = 0.f;
+  ep_ret += r;
+  // 10. outputs, auto-reset
+  ss_info inf;
+  inf.ep_ret = ep_ret;
+  inf.ep_len = (float)elapsed;
+  inf.bad_transition = bad;
+  inf.steps_reached = n;
+  inf.update_terrain = advanced;
+  if (d && P.auto_reset) {
+    env_reset<Model>(P, e, s, c, ctr, pot_prev, z_init, nn_dr);
+    n = 1; count = 0; elapsed = 0; flags = 0; ep_ret = 0.f;
+  }
+  if (valid) {
+    float o[SS_OBS_DIM];
+    write_obs<Model>(s, z_init, flags, c, o);
+    float* op = io.obs + (size_t)e * SS_OBS_DIM;
+#pragma unroll
+    for (int i = 0; i < SS_OBS_DIM; ++i) op[i] = o[i];
+    io.rew[e] = r;
+    io.done[e] = d ? 1 : 0;
+    if (io.info) io.info[e] = inf;
+    store_dyn(P, e, s);
+    if (advanced || d) store_cache(P, e, c);
+    P.fstate[e + F_POT * np] = pot_prev;
+    P.fstate[e + F_ZINIT * np] = z_init;
+    P.fstate[e + F_EPRET * np] = ep_ret;
+    P.fstate[e + F_NNDR * np] = nn_dr;
+    P.istate[e + I_N * np] = n;
+    P.istate[e + I_COUNT * np] = count;
+    P.istate[e + I_ELAPSED * np] = elapsed;
+    P.istate[e + I_RNG * np] = (int)ctr;
+    P.istate[e + I_FLAGS * np] = flags;
+  }
+}
+
+#ifndef SS_HOST_HARNESS
+template <class Model, bool RANDOM_ACT>
+__global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
+  __shared__ float4 lds4[kLdsSlots * kWave];
+  step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, lds4);
+}
+#endif  // SS_HOST_HARNESS
+
+#ifndef SS_HOST_HARNESS
+template <class Model>
+__global__ __launch_bounds__(kWave) void reset_kernel(Params P, float* obs) {
+  const int e = blockIdx.x * kWave + threadIdx.x;
+  if (e >= P.n) return;
+  const size_t np = (size_t)P.npad;
+  Dyn s;
+  Cache c;
+  uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
+  float pot, z_init, nn_dr;
+  env_reset<Model>(P, e, s, c, ctr, pot, z_init, nn_dr);
+  store_dyn(P, e, s);
+  store_cache(P, e, c);
+  P.fstate[e + F_POT * np] = pot;
+  P.fstate[e + F_ZINIT * np] = z_init;
+  P.fstate[e + F_EPRET * np] = 0.f;
+  P.fstate[e + F_NNDR * np] = nn_dr;
+  P.istate[e + I_N * np] = 1;
+  P.istate[e + I_COUNT * np] = 0;
+  P.istate[e + I_ELAPSED * np] = 0;
+  P.istate[e + I_RNG * np] = (int)ctr;
+  P.istate[e + I_FLAGS * np] = 0;
+  if (obs) {
+    float o[SS_OBS_DIM];
+    write_obs<Model>(s, z_init, 0, c, o);
+#pragma unroll
+    for (int i = 0; i < SS_OBS_DIM; ++i) obs[(size_t)e * SS_OBS_DIM + i] = o[i];
+  }
+}
+#endif  // SS_HOST_HARNESS
+
+#ifndef SS_HOST_HARNESS
+template <class Model>
+__global__ __launch_bounds__(kWave) void obs_kernel(Params P, float* obs) {
+  const int e = blockIdx.x * kWave + threadIdx.x;
+  if (e >= P.n) return;
+  const size_t np = (size_t)P.npad;
+  Dyn s;
+  Cache c;
+  load_dyn(P, e, s);
+  load_cache(P, e, c);
+  float o[SS_OBS_DIM];
+  write_obs<Model>(s, P.fstate[e + F_ZINIT * np], P.istate[e + I_FLAGS * np], c, o);
+#pragma unroll
+  for (int i = 0; i < SS_OBS_DIM; ++i) obs[(size_t)e * SS_OBS_DIM + i] = o[i];
+}
+#endif  // SS_HOST_HARNESS
+
+// one thread per (env, grid cell): PHYSICS.md section 8
+#ifndef SS_HOST_HARNESS
+template <class Model>
+__global__ __launch_bounds__(256) void temp_states_kernel(Params P, float* out) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= P.n * SS_NCELL) return;
+  const int e = tid / SS_NCELL, cell = tid % SS_NCELL;
+  const size_t np = (size_t)P.npad;
+  Dyn s;
+  Cache c;
+  load_dyn(P, e, s);
+  load_cache(P, e, c);
+  int n = P.istate[e + I_N * np];
+  if (n + 1 <= kNumStones - 1) {
+    const float* T = P.terrain + e;
+    float phi = T[(n * 6 + 3) * np] + yaw_sample(cell / SS_GRID), pitch = pitch_sample(cell % SS_GRID);
+    float dr = P.fstate[e + F_NNDR * np];
+    float sp, cp, sph, cph;
+    sincosf(pitch, &sp, &cp);
+    sincosf(phi, &sph, &cph);
+    float planar = dr * cp;
+    c.p[2][0] = c.p[1][0] + planar * cph;
+    c.p[2][1] = c.p[1][1] + planar * sph;
+    c.p[2][2] = c.p[1][2] + dr * sp;
+  }
+  float o[SS_OBS_DIM];
+  write_obs<Model>(s, P.fstate[e + F_ZINIT * np], P.istate[e + I_FLAGS * np], c, o);
+  float* op = out + (size_t)tid * SS_OBS_DIM;
+#pragma unroll
+  for (int i = 0; i < SS_OBS_DIM; ++i) op[i] = o[i];
+}
+#endif  // SS_HOST_HARNESS
+
+#ifndef SS_HOST_HARNESS
+__global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)(6u * (uint32_t)t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int j = b * 4 + i;
+      if (j < NJ) act[(size_t)e * NJ + j] = 2.f * u01(r[i]) - 1.f;
+    }
+  }
+}
+#endif  // SS_HOST_HARNESS
+
+// packed [N,185] <-> structure of arrays (PHYSICS / include/steppingstone.h layout)
+SSD void pack_env(const Params& P, int e, float* packed) {
+  const size_t np = (size_t)P.npad;
+  float* o = packed + (size_t)e * SS_STATE_DIM;
+  for (int i = 0; i < 59; ++i) o[i] = P.fstate[e + (size_t)i * np];
+  o[59] = (float)P.istate[e + I_N * np];
+  o[60] = (float)P.istate[e + I_COUNT * np];
+  o[61] = (float)P.istate[e + I_ELAPSED * np];
+  uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
+  o[62] = (float)(ctr & 0xFFFFu);
+  o[63] = (float)(ctr >> 16);
+  o[64] = (float)P.istate[e + I_FLAGS * np];
+  for (int i = 0; i < 120; ++i) o[65 + i] = P.terrain[e + (size_t)i * np];
+}
+SSD void unpack_env(const Params& P, int e, const float* packed) {
+  const size_t np = (size_t)P.npad;
+  const float* o = packed + (size_t)e * SS_STATE_DIM;
+  for (int i = 0; i < 59; ++i) P.fstate[e + (size_t)i * np] = o[i];
+  int n = (int)o[59];
+  P.istate[e + I_N * np] = n;
+  P.istate[e + I_COUNT * np] = (int)o[60];
+  P.istate[e + I_ELAPSED * np] = (int)o[61];
+  P.istate[e + I_RNG * np] = (int)((uint32_t)o[62] | ((uint32_t)o[63] << 16));
+  P.istate[e + I_FLAGS * np] = (int)o[64];
+  for (int i = 0; i < 120; ++i) P.terrain[e + (size_t)i * np] = o[65 + i];
+  Cache c;
+  cache_from_terrain(P, e, n, c);
+  store_cache(P, e, c);
+}
+#ifndef SS_HOST_HARNESS
+__global__ void pack_state_kernel(Params P, float* packed) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < P.n) pack_env(P, e, packed);
+}
+#endif  // SS_HOST_HARNESS
+#ifndef SS_HOST_HARNESS
+__global__ void unpack_state_kernel(Params P, const float* packed) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < P.n) unpack_env(P, e, packed);
+}
+#endif  // SS_HOST_HARNESS
+
+}  // namespace ss

@@ -1,0 +1,434 @@
+"""Host-side mirror of the reference's env / vec-env protocol for the stepping-stone hot path.
+
+Drop-in surface (names, argument meaning, error behaviour) follows what `playground/train.py` and
+`playground/enjoy.py` of the reference consume through `common/envs_utils.py`:
+
+  make_env(env_id)                      common/envs_utils.py:43-45
+  make_vec_envs(env_id, seed, n, dir)   common/envs_utils.py:48-56
+  VecEnv.reset/step_async/step_wait/step, update_curriculum, update_specialist, update_sample_prob,
+  create_temp_states, set_mirror, set_env_params, set_robot_params, close   common/envs_utils.py:542-606
+
+Instead of N worker processes with pipes and shared memory, all N environments live in HBM on one MI355X and one
+kernel launch advances them together.  PyTorch is plumbing only (device buffers + current stream); the arithmetic
+is in libsteppingstone.so (hand-written HIP).  There is NO CPU implementation in this package.
+"""
+import ctypes as C
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_DIM, GRID, MAX_EPISODE_STEPS, NCELL, NUM_STONES, OBS_DIM, STATE_DIM, SteppingStoneError
+
+DEG = np.pi / 180.0
+ENV_KINDS = {
+    "Walker3DStepperEnv-v0": _lib.WALKER3D, "mocca_envs:Walker3DStepperEnv-v0": _lib.WALKER3D,
+    "MikeStepperEnv-v0": _lib.MIKE, "mocca_envs:MikeStepperEnv-v0": _lib.MIKE,
+}
+_EMPTY_INFO = types.MappingProxyType({})
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency): shape/dtype/low/high."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.low = np.full(self.shape, low, self.dtype)
+        self.high = np.full(self.shape, high, self.dtype)
+
+    def sample(self):
+        lo = np.where(np.isfinite(self.low), self.low, -1.0)
+        hi = np.where(np.isfinite(self.high), self.high, 1.0)
+        return np.random.uniform(lo, hi).astype(self.dtype)
+
+    def __repr__(self):
+        return "Box%s" % (self.shape,)
+
+
+class EnvSpec:
+    def __init__(self, env_id):
+        self.id = env_id
+        self.max_episode_steps = MAX_EPISODE_STEPS
+
+
+def kind_of(env_id):
+    if env_id not in ENV_KINDS:
+        raise SteppingStoneError("unknown env id %r (known: %s)" % (env_id, ", ".join(sorted(ENV_KINDS))))
+    return ENV_KINDS[env_id]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class HipBackend:
+    """Owns one ss_env handle on one GPU.  All tensor arguments must be contiguous tensors on `self.device`."""
+
+    def __init__(self, kind, num_envs, seed, device, env_id_offset=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise SteppingStoneError("no GPU visible to torch: the stepping-stone env runs on MI355X only "
+                                     "(there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise SteppingStoneError("device must be a cuda (HIP) device, got %s" % (self.device,))
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.n = int(num_envs)
+        h = C.c_void_p()
+        _lib.check(self.lib.ss_create(C.byref(h), int(kind), self.n, idx, int(seed) & (2 ** 64 - 1), int(env_id_offset)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ss_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, obs):
+        _lib.check(self.lib.ss_reset(self.h, _ptr(obs), _stream(self.device)))
+
+    def step(self, act, obs, rew, done, info):
+        _lib.check(self.lib.ss_step(self.h, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done), _ptr(info), _stream(self.device)))
+
+    def rollout_random(self, num_steps, t0, obs, rew, done, info):
+        _lib.check(self.lib.ss_rollout_random(self.h, int(num_steps), int(t0), _ptr(obs), _ptr(rew), _ptr(done),
+                                              _ptr(info), _stream(self.device)))
+
+    def random_actions(self, t, act):
+        _lib.check(self.lib.ss_random_actions(self.h, int(t), _ptr(act), _stream(self.device)))
+
+    def set_curriculum(self, level):
+        _lib.check(self.lib.ss_set_curriculum(self.h, int(level)))
+
+    def set_specialist(self, level):
+        _lib.check(self.lib.ss_set_specialist(self.h, int(level)))
+
+    def set_sample_prob(self, prob, per_env):
+        prob = np.ascontiguousarray(prob, np.float64)
+        _lib.check(self.lib.ss_set_sample_prob(self.h, prob.ctypes.data_as(C.c_void_p), 1 if per_env else 0))
+
+    def set_mirror(self, on):
+        _lib.check(self.lib.ss_set_mirror(self.h, 1 if on else 0))
+
+    def set_power(self, power):
+        _lib.check(self.lib.ss_set_power(self.h, float(power)))
+
+    def set_auto_reset(self, on):
+        _lib.check(self.lib.ss_set_auto_reset(self.h, 1 if on else 0))
+
+    def create_temp_states(self, out):
+        _lib.check(self.lib.ss_create_temp_states(self.h, _ptr(out), _stream(self.device)))
+
+    def get_state(self, packed):
+        _lib.check(self.lib.ss_get_state(self.h, _ptr(packed), _stream(self.device)))
+
+    def set_state(self, packed):
+        _lib.check(self.lib.ss_set_state(self.h, _ptr(packed), _stream(self.device)))
+
+    def get_obs(self, obs):
+        _lib.check(self.lib.ss_get_obs(self.h, _ptr(obs), _stream(self.device)))
+
+
+class SteppingStoneVecEnv:
+    """N stepping-stone environments advanced by one HIP kernel launch per step.
+
+    return_numpy=True reproduces the reference's ShmemVecEnv return types exactly (obs float32 (N,60) ndarray,
+    rews float64 (N,), dones bool (N,), infos sequence of N dicts; common/envs_utils.py:555-558) so that
+    playground/train.py consumes it unchanged; return_numpy=False keeps everything on the GPU (obs/rew/done
+    tensors, infos as a dict of tensors) for a device-resident PPO loop.
+    """
+
+    closed = False
+
+    def __init__(self, env_id, num_envs, seed=0, device=None, env_id_offset=0, return_numpy=False, backend=None):
+        self.env_id = env_id
+        self.kind = kind_of(env_id)
+        self.num_envs = int(num_envs)
+        self.seed_value = int(seed)
+        self.return_numpy = bool(return_numpy)
+        self.spec = EnvSpec(env_id)
+        high = np.inf
+        self.observation_space = Box(-high, high, (OBS_DIM,), np.float32)
+        self.action_space = Box(-1.0, 1.0, (ACT_DIM,), np.float32)
+        # `backend` is a test seam (tests inject an oracle-backed object); the product path is always HIP.
+        self.backend = backend if backend is not None else HipBackend(self.kind, num_envs, seed, device, env_id_offset)
+        dev = self.backend.device
+        self.device = dev
+        n = self.num_envs
+        self._obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=dev)
+        self._rew = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        self._info = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+        self._act = torch.zeros((n, ACT_DIM), dtype=torch.float32, device=dev)
+        self._pending = False
+        self._tstart = time.time()
+        self.yaw_samples = np.linspace(-20.0, 20.0, GRID) * DEG
+        self.pitch_samples = np.linspace(-30.0, 30.0, GRID) * DEG
+        self.yaw_sample_size = GRID
+        self.pitch_sample_size = GRID
+        self._max_episode_steps = MAX_EPISODE_STEPS
+        self.curriculum = 0
+
+    # ------------------------------------------------------------------ gym / VecEnv protocol
+    def reset(self):
+        if self._pending:
+            print("Called reset() while waiting for the step to complete")
+            self.step_wait()
+        self.backend.reset(self._obs)
+        return self._out_obs()
+
+    def step_async(self, actions):
+        if torch.is_tensor(actions):
+            a = actions.to(device=self.device, dtype=torch.float32)
+        else:
+            a = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+        assert a.shape[0] == self.num_envs, "expected %d actions, got %d" % (self.num_envs, a.shape[0])
+        self._act.copy_(a.reshape(self.num_envs, ACT_DIM))
+        self.backend.step(self._act, self._obs, self._rew, self._done, self._info)
+        self._pending = True
+
+    def step_wait(self):
+        self._pending = False
+        if not self.return_numpy:
+            return self._obs, self._rew, self._done.bool(), self._info_tensors()
+        obs = self._obs.cpu().numpy()
+        rew = self._rew.cpu().numpy().astype(np.float64)
+        done = self._done.cpu().numpy().astype(bool)
+        return obs, rew, done, self._info_dicts(done)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def rollout_random(self, num_steps, t0=0):
+        """BASELINE metric path: num_steps launches with on-device U(-1,1) actions (Philox stream 1)."""
+        self.backend.rollout_random(num_steps, t0, self._obs, self._rew, self._done, self._info)
+        return self._obs, self._rew, self._done
+
+    def random_actions(self, t):
+        self.backend.random_actions(t, self._act)
+        return self._act.clone()
+
+    def close(self):
+        if self.closed:
+            return
+        self.backend.close()
+        self.closed = True
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope for the GPU env")
+
+    def get_images(self):
+        raise NotImplementedError("rendering is out of scope for the GPU env")
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ------------------------------------------------------------------ curriculum hooks
+    def update_curriculum(self, curriculum):
+        self.curriculum = int(curriculum)
+        self.backend.set_curriculum(min(max(self.curriculum, 0), 5))
+
+    def update_specialist(self, specialist):
+        self.curriculum = int(specialist)
+        self.backend.set_specialist(min(max(int(specialist), 0), 5))
+
+    def update_sample_prob(self, probs):
+        """probs: (N,11,11) one grid per env (playground/train.py:267-271) or a single (11,11) grid."""
+        probs = np.asarray(probs, np.float64)
+        if probs.shape == (GRID, GRID):
+            self.backend.set_sample_prob(probs, False)
+        elif probs.shape == (self.num_envs, GRID, GRID):
+            same = self.num_envs == 1 or bool(np.all(probs == probs[0]))
+            self.backend.set_sample_prob(probs[0] if same else probs, not same)
+        else:
+            raise ValueError("sample_prob must have shape (%d,%d,%d) or (%d,%d), got %s"
+                             % (self.num_envs, GRID, GRID, GRID, GRID, probs.shape))
+
+    def create_temp_states(self):
+        out = torch.empty((self.num_envs, NCELL, OBS_DIM), dtype=torch.float32, device=self.device)
+        self.backend.create_temp_states(out)
+        return out.cpu().numpy() if self.return_numpy else out
+
+    def set_mirror(self, mirror):
+        self.backend.set_mirror(bool(mirror))
+
+    def set_env_params(self, params_dict):
+        for k, v in dict(params_dict).items():
+            if k == "curriculum":
+                self.update_curriculum(v)
+            else:
+                raise KeyError("unsupported env param %r" % (k,))
+
+    def set_robot_params(self, params_dict):
+        for k, v in dict(params_dict).items():
+            if k == "power":
+                self.backend.set_power(float(v))
+            else:
+                raise KeyError("unsupported robot param %r" % (k,))
+
+    def get_mirror_indices(self):
+        return _lib.mirror_indices(self.kind)
+
+    # ------------------------------------------------------------------ state access
+    def get_state(self):
+        st = torch.empty((self.num_envs, STATE_DIM), dtype=torch.float32, device=self.device)
+        self.backend.get_state(st)
+        return st
+
+    def set_state(self, packed):
+        st = torch.as_tensor(packed, dtype=torch.float32).to(self.device).contiguous().reshape(self.num_envs, STATE_DIM)
+        self.backend.set_state(st)
+
+    def get_obs(self):
+        self.backend.get_obs(self._obs)
+        return self._out_obs()
+
+    @property
+    def terrain_info(self):
+        """(N,20,6) x,y,z,phi,x_tilt,y_tilt (playground/enjoy.py:60-64)."""
+        return self.get_state()[:, 65:].reshape(self.num_envs, NUM_STONES, 6).cpu().numpy()
+
+    @property
+    def next_step_index(self):
+        return self.get_state()[:, 59].cpu().numpy().astype(np.int64)
+
+    # ------------------------------------------------------------------ helpers
+    def _out_obs(self):
+        return self._obs.cpu().numpy() if self.return_numpy else self._obs
+
+    def _info_tensors(self):
+        fl = self._info[:, 0:2].view(torch.float32)
+        return {"ep_ret": fl[:, 0], "ep_len": fl[:, 1], "bad_transition": self._info[:, 2],
+                "steps_reached": self._info[:, 3], "update_terrain": self._info[:, 4]}
+
+    def _info_dicts(self, done):
+        """Sequence of N info dicts with the reference's keys (common/envs_utils.py:59-65,131-153)."""
+        infos = [_EMPTY_INFO] * self.num_envs
+        idx = np.nonzero(done)[0]
+        if idx.size:
+            raw = self._info.cpu().numpy()
+            fl = raw[:, 0:2].view(np.float32)
+            now = round(time.time() - self._tstart, 6)
+            for i in idx:
+                d = {"episode": {"r": round(float(fl[i, 0]), 6), "l": int(fl[i, 1]), "t": now},
+                     "steps_reached": int(raw[i, 3])}
+                if raw[i, 2]:
+                    d["bad_transition"] = True
+                infos[i] = d
+        return tuple(infos)
+
+
+class _Robot:
+    def __init__(self):
+        self.feet_contact = np.zeros(2, np.float32)
+
+
+class SteppingStoneEnv:
+    """Single-env gym-style facade over a 1-env SteppingStoneVecEnv (what `make_env` returns in the reference;
+    playground/train.py:96,129-131,231-247 and playground/enjoy.py:101-102,231-235 use these members)."""
+
+    def __init__(self, env_id, seed=0, device=None, render=False, backend_factory=None):
+        if render:
+            raise NotImplementedError("rendering is out of scope for the GPU env")
+        self._env_id = env_id
+        self._device = device
+        self._backend_factory = backend_factory
+        self._make(seed)
+        self.robot = _Robot()
+        self.update_terrain = False
+        self.camera = None
+
+    def _make(self, seed):
+        backend = self._backend_factory(kind_of(self._env_id), 1, seed) if self._backend_factory else None
+        self.vec = SteppingStoneVecEnv(self._env_id, 1, seed=seed, device=self._device, return_numpy=True, backend=backend)
+        self.vec.backend.set_auto_reset(False)
+        self.observation_space = self.vec.observation_space
+        self.action_space = self.vec.action_space
+        self.spec = self.vec.spec
+        self.yaw_samples, self.pitch_samples = self.vec.yaw_samples, self.vec.pitch_samples
+        self.yaw_sample_size, self.pitch_sample_size = GRID, GRID
+        self._max_episode_steps = MAX_EPISODE_STEPS
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def seed(self, seed=None):
+        curriculum = self.vec.curriculum
+        self.vec.close()
+        self._make(0 if seed is None else int(seed))
+        self.vec.update_curriculum(curriculum)
+        return [seed]
+
+    def reset(self):
+        self.update_terrain = False
+        return self.vec.reset()[0]
+
+    def step(self, action):
+        obs, rew, done, infos = self.vec.step(np.asarray(action, np.float32).reshape(1, ACT_DIM))
+        raw = self.vec._info.cpu().numpy()[0]
+        self.update_terrain = bool(raw[4])
+        self.robot.feet_contact[:] = obs[0, 48:50]
+        info = dict(infos[0])
+        return obs[0], float(rew[0]), bool(done[0]), info
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope for the GPU env")
+
+    def close(self):
+        self.vec.close()
+
+    def update_curriculum(self, curriculum):
+        self.vec.update_curriculum(curriculum)
+
+    def update_specialist(self, specialist):
+        self.vec.update_specialist(specialist)
+
+    def update_sample_prob(self, prob):
+        self.vec.update_sample_prob(np.asarray(prob, np.float64).reshape(GRID, GRID))
+
+    def set_mirror(self, mirror):
+        self.vec.set_mirror(mirror)
+
+    def create_temp_states(self):
+        return self.vec.create_temp_states()[0]
+
+    def get_mirror_indices(self):
+        return self.vec.get_mirror_indices()
+
+    @property
+    def terrain_info(self):
+        return self.vec.terrain_info[0]
+
+    @property
+    def next_step_index(self):
+        return int(self.vec.next_step_index[0])
+
+
+def make_env(env_id, render=False, seed=0, device=None):
+    """Counterpart of common/envs_utils.py:43-45."""
+    return SteppingStoneEnv(env_id, seed=seed, device=device, render=render)
+
+
+def make_vec_envs(env_id, seed, num_processes, log_dir=None, device=None, return_numpy=True, env_id_offset=0):
+    """Counterpart of common/envs_utils.py:48-56: `num_processes` environments with seeds seed+rank.  The reference
+    forks one process per env; here they are lanes of one kernel on `device`.  (log_dir is accepted for signature
+    compatibility; episode returns arrive in info["episode"] exactly as Monitor delivers them.)"""
+    assert num_processes > 1
+    return SteppingStoneVecEnv(env_id, num_processes, seed=seed, device=device, env_id_offset=env_id_offset,
+                               return_numpy=return_numpy)

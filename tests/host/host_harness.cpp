@@ -1,0 +1,54 @@
+// host_harness.cpp -- compiles the SAME kernel source (steppingstone_amd/csrc/*.hpp) for the CPU so that the
+// per-lane device code can be checked against the oracle in the GPU-less build container (pre-flight / debugging).
+// TEST INFRASTRUCTURE ONLY: it is built by tests/host_lib.py into tests/host/, never shipped, and the product
+// library contains no host path.  Build: hipcc --cuda-host-only -x hip ... (see tests/host_lib.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../steppingstone_amd/csrc/ss_kernels.hpp"
+
+namespace {
+void window_prob(float* p, int c) {
+  int cnt = 0;
+  for (int i = 0; i < 11; ++i)
+    for (int j = 0; j < 11; ++j) {
+      int di = std::abs(i - 5), dj = std::abs(j - 5), m = di > dj ? di : dj;
+      p[i * 11 + j] = (m <= c) ? 1.f : 0.f;
+      cnt += (m <= c);
+    }
+  for (int k = 0; k < 121; ++k) p[k] /= (float)cnt;
+}
+}  // namespace
+
+extern "C" {
+
+// one control step of n envs: packed state in/out [n,185], act [n,21]; outputs obs [n,60], rew, done, info
+int hh_step(int kind, int n, unsigned long long seed, int curriculum, const double* prob /*121 or null*/,
+            const float* packed_in, const float* act, float* packed_out, float* obs, float* rew,
+            unsigned char* done, ss_info* info) {
+  ss::Params P;
+  std::memset(&P, 0, sizeof P);
+  P.n = n;
+  P.npad = (n + 63) / 64 * 64;
+  std::vector<float> f((size_t)ss::NF * P.npad, 0.f), terr((size_t)120 * P.npad, 0.f), pr(121);
+  std::vector<int> is((size_t)ss::NI * P.npad, 0);
+  window_prob(pr.data(), curriculum);
+  if (prob) for (int k = 0; k < 121; ++k) pr[k] = (float)prob[k];
+  P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.prob = pr.data();
+  P.per_env_prob = 0; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
+  P.curriculum = curriculum; P.power = 1.f; P.auto_reset = 1;
+  std::vector<float4> lds((size_t)ss::kLdsSlots * 64);
+  ss::StepIO io{act, obs, rew, done, info, 0};
+  for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
+  for (int e = 0; e < n; ++e) {
+    if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, e, e % 64, lds.data());
+    else ss::step_env<ss::ModelMike, false>(P, io, e, e % 64, lds.data());
+  }
+  for (int e = 0; e < n; ++e) ss::pack_env(P, e, packed_out);
+  return 0;
+}
+
+}  // extern "C"

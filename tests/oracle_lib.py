@@ -49,6 +49,7 @@ def load(prec="f32"):
     lib.sso_set_specialist.argtypes = [vp, i32]
     lib.sso_set_sample_prob.argtypes = [vp, vp, i32]
     lib.sso_set_power.argtypes = [vp, dbl]
+    lib.sso_set_auto_reset.argtypes = [vp, i32]
     lib.sso_create_temp_states.argtypes = [vp, vp]
     lib.sso_get_state.argtypes = [vp, vp]
     lib.sso_set_state.argtypes = [vp, vp]
@@ -115,6 +116,9 @@ class OracleEnv:
 
     def set_power(self, power):
         self.lib.sso_set_power(self.h, float(power))
+
+    def set_auto_reset(self, on):
+        self.lib.sso_set_auto_reset(self.h, 1 if on else 0)
 
     def create_temp_states(self):
         out = np.zeros((self.n, NCELL, OBS_DIM), np.float32)

@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP path (through the C ABI, via steppingstone_amd.envs) against the CPU oracle on the
+same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (fp32, stated here as required by the task brief):
+  * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, done,
+    bad_transition, update_terrain): bit-exact;
+  * one control step from an identical injected state (4 substeps, different operation order and libm):
+    |obs| 2e-3 abs on the +-5-clipped observation, state 2e-3 abs / 2e-3 rel, reward 2e-2 abs -- required of
+    >= 99.5 % of env-steps, because a contact that is within rounding of opening/closing legitimately flips the
+    discrete contact set (those env-steps are reported, not hidden);
+  * free-running 1000-step drift is chaotic (contacts make/break) and is characterised, not bounded, beyond the
+    first 5 steps.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+KINDS = [("Walker3DStepperEnv-v0", "walker3d"), ("MikeStepperEnv-v0", "mike")]
+INT_FIELDS = [ol.S_N, ol.S_COUNT, ol.S_ELAPSED, ol.S_CTRLO, ol.S_CTRHI, ol.S_FLAGS]
+
+
+def gpu_env(env_id, n, seed=0, **kw):
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    return SteppingStoneVecEnv(env_id, n, seed=seed, device="cuda:0", return_numpy=True, **kw)
+
+
+def test_library_loaded_is_in_tree():
+    from steppingstone_amd import _lib
+    lib = _lib.load()
+    assert lib.ss_version() >= 1
+    assert _lib.LIB_PATH.endswith("steppingstone_amd/lib/libsteppingstone.so")
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_reset_matches_oracle(env_id, kind):
+    n = 200   # not a multiple of 64 on purpose (ragged last wavefront)
+    g = gpu_env(env_id, n, seed=7)
+    o = ol.OracleEnv(kind, n, seed=7)
+    og, oo = g.reset(), o.reset()
+    assert og.shape == (n, 60) and og.dtype == np.float32
+    assert np.abs(og - oo).max() < 1e-6
+    sg, so = g.get_state().cpu().numpy(), o.get_state()
+    assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS])
+    assert np.abs(sg - so).max() < 1e-6
+    g.close()
+
+
+def test_random_action_stream_is_bit_exact():
+    g = gpu_env("Walker3DStepperEnv-v0", 130, seed=3)
+    o = ol.OracleEnv("walker3d", 130, seed=3)
+    for t in (0, 1, 17, 100000):
+        assert np.array_equal(g.random_actions(t).cpu().numpy(), o.random_actions(t))
+    g.close()
+
+
+def _step_parity(env_id, kind, n, steps, seed, curriculum=0):
+    g = gpu_env(env_id, n, seed=seed)
+    o = ol.OracleEnv(kind, n, seed=seed)
+    if curriculum:
+        g.update_curriculum(curriculum)
+        o.set_curriculum(curriculum)
+    g.reset()
+    o.reset()
+    bad = 0
+    worst = dict(obs=0.0, state=0.0, rew=0.0)
+    total = 0
+    for t in range(steps):
+        st = o.get_state()
+        g.set_state(st)
+        a = o.random_actions(t)
+        oo, ro, do, io = o.step(a)
+        og, rg, dg, ig = g.step(a)
+        sg, so = g.get_state().cpu().numpy(), o.get_state()
+        raw = g._info.cpu().numpy()
+        e_obs = np.abs(og - oo).max(axis=1)
+        tol_state = 2e-3 + 2e-3 * np.abs(so)
+        e_state = (np.abs(sg - so) / tol_state).max(axis=1)
+        e_rew = np.abs(rg - ro)
+        ints_ok = (sg[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1) & (dg == do.astype(bool)) & \
+                  (raw[:, 2] == io["bad_transition"]) & (raw[:, 4] == io["update_terrain"])
+        ok = (e_obs < 2e-3) & (e_state < 1.0) & (e_rew < 2e-2) & ints_ok
+        bad += int((~ok).sum())
+        total += n
+        if ok.any():
+            worst["obs"] = max(worst["obs"], float(e_obs[ok].max()))
+            worst["state"] = max(worst["state"], float(e_state[ok].max()))
+            worst["rew"] = max(worst["rew"], float(e_rew[ok].max()))
+    g.close()
+    return bad, total, worst
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_single_step_parity_from_injected_state(env_id, kind):
+    bad, total, worst = _step_parity(env_id, kind, n=256, steps=60, seed=11)
+    print("single-step parity %s: %d/%d env-steps outside tolerance; worst in-tolerance errors %s"
+          % (kind, bad, total, worst))
+    assert bad <= 0.005 * total, (bad, total, worst)
+
+
+def _stand_on_target(o, n_envs):
+    """Oracle state with every robot standing on its target stone (stone 1), so the target-advance / stone-draw
+    path runs within two steps."""
+    st = o.get_state()
+    st[:, 0] = st[:, 65 + 6 + 0]          # x := stone 1 x
+    st[:, ol.S_POT] = 0.0
+    o.set_state(st)
+    return st
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_target_advance_and_sampler_are_bit_exact(env_id, kind):
+    n = 192
+    g = gpu_env(env_id, n, seed=5)
+    o = ol.OracleEnv(kind, n, seed=5)
+    rng = np.random.default_rng(0)
+    probs = rng.random((n, 11, 11))
+    probs /= probs.sum(axis=(1, 2), keepdims=True)
+    for env in (g,):
+        env.update_curriculum(5)
+        env.update_sample_prob(probs)
+    o.set_curriculum(5)
+    o.set_sample_prob(probs)
+    g.reset()
+    o.reset()
+    g.set_state(_stand_on_target(o, n))
+    zero = np.zeros((n, 21), np.float32)
+    advanced = np.zeros(n, bool)
+    for t in range(3):
+        oo, ro, do, io = o.step(zero)
+        og, rg, dg, ig = g.step(zero)
+        raw = g._info.cpu().numpy()
+        assert np.array_equal(raw[:, 4], io["update_terrain"])
+        assert np.array_equal(raw[:, 3], io["steps_reached"])
+        advanced |= io["update_terrain"].astype(bool)
+        sg, so = g.get_state().cpu().numpy(), o.get_state()
+        assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS])
+        # the drawn stone (terrain rows) must agree to rounding; the sampled cell is discrete, so a wrong cell
+        # would show up as a >= 4 degree / 6 degree jump
+        assert np.abs(sg[:, 65:] - so[:, 65:]).max() < 1e-5
+        g.set_state(so)
+    assert advanced.mean() > 0.5     # a torque-free robot keeps a foot on the stone for 2 steps in most envs
+    # step bonus was paid on first touch: reward parity covers it
+    g.close()
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_create_temp_states_matches_oracle(env_id, kind):
+    n = 70
+    g = gpu_env(env_id, n, seed=9)
+    o = ol.OracleEnv(kind, n, seed=9)
+    g.update_curriculum(3)
+    o.set_curriculum(3)
+    g.reset()
+    o.reset()
+    for t in range(3):
+        a = o.random_actions(t)
+        o.step(a)
+    g.set_state(o.get_state())
+    tg, to = g.create_temp_states(), o.create_temp_states()
+    assert tg.shape == (n, 121, 60)
+    assert np.abs(tg - to).max() < 2e-5
+    # only the look-ahead block differs between grid cells
+    assert np.abs(tg[:, 1:, :55] - tg[:, :1, :55]).max() == 0.0
+    g.close()
+
+
+def test_free_run_drift_is_characterised():
+    """Both sides free-run from the same seed; divergence is chaotic once contacts differ.  Assert the short
+    horizon and print the curve for DESIGN.md."""
+    n = 256
+    g = gpu_env("Walker3DStepperEnv-v0", n, seed=21)
+    o = ol.OracleEnv("walker3d", n, seed=21)
+    g.reset()
+    o.reset()
+    curve = []
+    alive = np.ones(n, bool)
+    for t in range(200):
+        a = o.random_actions(t)
+        oo, ro, do, _ = o.step(a)
+        og, rg, dg, _ = g.step(a)
+        alive &= ~(do.astype(bool) | dg)
+        if alive.sum() == 0:
+            break
+        err = np.abs(og - oo).max(axis=1)
+        curve.append((t, int(alive.sum()), float(np.median(err[alive])), float(err[alive].max())))
+    print("free-run |obs| divergence (step, alive, median, max):", curve[:5], "...", curve[-3:])
+    assert curve[4][3] < 5e-2 and curve[4][2] < 2e-3
+    g.close()
+
+
+@pytest.mark.parametrize("env_id", ["Walker3DStepperEnv-v0", "MikeStepperEnv-v0"])
+def test_full_size_rollout_properties(env_id):
+    """BASELINE size (4096 envs): size-independent invariants of a random-action rollout."""
+    n = 4096
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    g = SteppingStoneVecEnv(env_id, n, seed=1, device="cuda:0", return_numpy=False)
+    g.update_curriculum(5)
+    g.reset()
+    ndone = 0
+    for t in range(80):
+        obs, rew, done = g.rollout_random(1, t0=t)
+        info = g._info_tensors()
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert (obs[:, :50].abs() <= 5.0).all()
+        d = done.bool()
+        ndone += int(d.sum())
+        st = g.get_state()
+        qn = st[:, 3:7].norm(dim=1)
+        assert (qn - 1).abs().max() < 1e-4
+        # auto-reset: finished envs restart at elapsed 0 with the reset pose, the others count up
+        assert (st[d, 61] == 0).all()
+        assert (info["ep_len"][d] >= 1).all()
+        assert (st[:, 59] >= 1).all() and (st[:, 59] <= 19).all()
+    assert ndone > n        # every env fell at least once in 80 random steps on average
+    g.close()
+
+
+def test_rollout_matches_step_with_explicit_actions():
+    n = 128
+    a_env = gpu_env("Walker3DStepperEnv-v0", n, seed=4)
+    b_env = gpu_env("Walker3DStepperEnv-v0", n, seed=4)
+    a_env.reset()
+    b_env.reset()
+    for t in range(5):
+        oa, ra, da = a_env.rollout_random(1, t0=t)
+        ob, rb, db, _ = b_env.step(b_env.random_actions(t))
+        # two template instantiations of the same kernel (on-device vs explicit actions): identical actions,
+        # fp contraction may differ in the last bits
+        assert np.abs(oa.cpu().numpy() - ob).max() < 1e-4
+        assert np.abs(ra.cpu().numpy().astype(np.float64) - rb).max() < 1e-3
+    a_env.close()
+    b_env.close()
+
+
+def test_single_env_facade_and_errors():
+    from steppingstone_amd import SteppingStoneError
+    from steppingstone_amd.envs import make_env
+    env = make_env("mocca_envs:Walker3DStepperEnv-v0")
+    env.seed(1093)
+    obs = env.reset()
+    assert obs.shape == (60,) and obs.dtype == np.float32
+    o2, r, d, info = env.step(np.zeros(21, np.float32))
+    assert isinstance(r, float) and isinstance(d, bool) and isinstance(info, dict)
+    assert env.create_temp_states().shape == (121, 60)
+    assert env.yaw_samples.shape == (11,) and env.pitch_samples.shape == (11,)
+    assert env.terrain_info.shape == (20, 6)
+    # no auto-reset for the plain gym facade: run to termination and check the terminal obs is NOT a reset obs
+    for _ in range(200):
+        o2, r, d, info = env.step(np.zeros(21, np.float32))
+        if d:
+            break
+    assert d and "episode" in info
+    assert abs(o2[0]) > 0.05     # torso height changed: terminal observation, not the reset pose
+    env.close()
+    with pytest.raises(SteppingStoneError):
+        make_env("NoSuchEnv-v0")
