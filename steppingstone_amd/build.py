@@ -14,11 +14,13 @@ LIB = os.path.join(LIBDIR, "libsteppingstone.so")
 SOURCES = ["ss_api.hip"]
 HEADERS = ["ss_math.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "ss_model_tables.hpp",
            os.path.join("..", "..", "include", "steppingstone.h")]
-# Plain IEEE -O3.  No fast-math family flags: -ffinite-math-only would delete the non-finite guard of PHYSICS.md 4.8,
-# and the combination -fno-signed-zeros -fno-math-errno -fno-trapping-math was measured (round 1) to produce a
-# wrong, run-to-run varying step_kernel on gfx950 with ROCm 7.2 while -O1 and plain -O3 match the oracle to 1e-7.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
-
+# IEEE -O3 without the SLP vectorizer.  Measured in round 1 on gfx950 / ROCm 7.2 (tools/gpu_debug2.py):
+#   * with SLP vectorisation (packed v_pk_fma_f32 / v_pk_mul_f32) the 28k-instruction step kernel is MISCOMPILED at
+#     -O2/-O3 (wrong and run-to-run varying results); -O1 and -O3 -fno-slp-vectorize match the oracle to 2e-7;
+#   * -fno-signed-zeros triggers the same failure even at plain -O3;
+#   * packed f32 VALU is not a throughput win on gfx950 anyway (MI355X_MICROARCH.md, per-instruction constants).
+# No fast-math family flags: -ffinite-math-only would delete the non-finite guard of PHYSICS.md 4.8.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
 
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):

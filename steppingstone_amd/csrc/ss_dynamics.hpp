@@ -10,8 +10,16 @@
 //           LDS, 8 projected Gauss-Seidel sweeps in the 12-dim foot-twist space, one whole-tree impulse
 //           response to apply the foot wrenches
 //   integrate (semi-implicit Euler)
-// LDS is used as per-lane private storage: slot-major float4 columns, lane stride 16 B (conflict-free
-// ds_read_b128 / ds_write_b128, no barriers because a workgroup is a single wavefront).
+//
+// Register / LDS budget.  One wavefront per workgroup, one workgroup per CU: each lane owns 512 VGPR+AGPR and a
+// private 2560-byte column of the CU's 160 KiB LDS (slot-major float4, lane stride 16 B: every ds_read/write_b128
+// is conflict-free and no barrier is ever needed).  What does not fit the register file lives in that column:
+//   slots   0..43   link velocities (ABA phase)        aliased with
+//   slots   0..35   Lambda^-1 columns (contact phase)
+//   slots  36..131  24 contact rows x 4 float4: y[12], dir[3], 1/A
+//   slots 132..133  normal-row targets b_n[8]
+//   slots 134..153  per-joint cache of the 8 arm joints (cs, sn, U[6], 1/D, u)
+//   slots 154..159  the 21 clipped actions of this control step
 #pragma once
 #include "ss_math.hpp"
 
@@ -27,10 +35,22 @@ constexpr float kSlop = 0.001f;
 constexpr float kVcorrMax = 2.0f;
 
 constexpr int kWave = 64;
-// LDS map (float4 slots per lane)
-constexpr int kLdsLinv = 0;            // 12 columns x 3 float4
-constexpr int kLdsRows = 36;           // 24 rows x 5 float4: y[12], w[6], 1/A, b
-constexpr int kLdsSlots = 36 + 120;    // 156 float4 = 2496 B per lane = 159,744 B per wavefront
+constexpr int kLdsVel = 0;
+constexpr int kLdsLinv = 0;
+constexpr int kLdsRows = 36;
+constexpr int kLdsBn = 132;
+constexpr int kLdsArms = 134;
+constexpr int kLdsAct = 154;
+constexpr int kLdsSlots = 160;         // 160 float4 = 2560 B per lane = 163,840 B per wavefront (all of the CU's LDS)
+constexpr int kNumLegJoints = 13;      // joints 0..12 (spine + legs) stay in registers, 13..20 (arms) live in LDS
+
+struct Lds {       // lane-private view of the workgroup's LDS
+  float4* base;
+  int lane;
+  SSD float4& q(int slot) const { return base[slot * kWave + lane]; }
+  SSD float& f(int slot, int comp) const { return reinterpret_cast<float*>(base + slot * kWave + lane)[comp]; }
+  SSD float& flat(int slot0, int idx) const { return f(slot0 + idx / 4, idx % 4); }
+};
 
 struct Dyn {       // dynamic state of one env
   float pos[3];
@@ -40,9 +60,8 @@ struct Dyn {       // dynamic state of one env
   float qd[NJ];
 };
 
-struct Stones {    // the three active stones n-1, n, n+1
-  float p[3][3];   // centre
-  float n[3][3];   // unit normal
+struct Stones {    // the three active stones n-1, n, n+1: centre, unit normal, tilts (x, y)
+  float p[3][3], nrm[3][3], tilt[3][2];
 };
 
 struct FootReport {
@@ -51,39 +70,88 @@ struct FootReport {
   float sole[2][3];
 };
 
-struct JointCache {  // kept from the ABA for the impulse responses
-  float cs[NJ], sn[NJ];
-  float Uw[NJ][3], Uv[NJ][3], Dinv[NJ];
+struct JRec {      // what the ABA leaves behind per joint
+  float cs, sn, Uw[3], Uv[3], Dinv, u;
+};
+struct JointCache {
+  JRec r[kNumLegJoints];
   Chol6 L0;
 };
 
-#define LDS4(slot) lds4[(slot) * kWave + lane]
+template <int J>
+SSD JRec jrec_get(const JointCache& jc, const Lds& L) {
+  if constexpr (J < kNumLegJoints) {
+    return jc.r[J];
+  } else {
+    constexpr int o = (J - kNumLegJoints) * 10;
+    JRec r;
+    r.cs = L.flat(kLdsArms, o + 0); r.sn = L.flat(kLdsArms, o + 1);
+    r.Uw[0] = L.flat(kLdsArms, o + 2); r.Uw[1] = L.flat(kLdsArms, o + 3); r.Uw[2] = L.flat(kLdsArms, o + 4);
+    r.Uv[0] = L.flat(kLdsArms, o + 5); r.Uv[1] = L.flat(kLdsArms, o + 6); r.Uv[2] = L.flat(kLdsArms, o + 7);
+    r.Dinv = L.flat(kLdsArms, o + 8); r.u = L.flat(kLdsArms, o + 9);
+    return r;
+  }
+}
+template <int J>
+SSD void jrec_put(JointCache& jc, const Lds& L, const JRec& r) {
+  if constexpr (J < kNumLegJoints) {
+    jc.r[J] = r;
+  } else {
+    constexpr int o = (J - kNumLegJoints) * 10;
+    L.flat(kLdsArms, o + 0) = r.cs; L.flat(kLdsArms, o + 1) = r.sn;
+    L.flat(kLdsArms, o + 2) = r.Uw[0]; L.flat(kLdsArms, o + 3) = r.Uw[1]; L.flat(kLdsArms, o + 4) = r.Uw[2];
+    L.flat(kLdsArms, o + 5) = r.Uv[0]; L.flat(kLdsArms, o + 6) = r.Uv[1]; L.flat(kLdsArms, o + 7) = r.Uv[2];
+    L.flat(kLdsArms, o + 8) = r.Dinv; L.flat(kLdsArms, o + 9) = r.u;
+  }
+}
+// cos / sin only (pass 1 runs before U, 1/D, u exist)
+template <int J>
+SSD void jcs_get(const JointCache& jc, const Lds& L, float& c, float& s) {
+  if constexpr (J < kNumLegJoints) { c = jc.r[J].cs; s = jc.r[J].sn; }
+  else { c = L.flat(kLdsArms, (J - kNumLegJoints) * 10 + 0); s = L.flat(kLdsArms, (J - kNumLegJoints) * 10 + 1); }
+}
+
+template <int B>
+SSD SV vel_get(const Lds& L) {
+  float4 a = L.q(kLdsVel + 2 * B), b = L.q(kLdsVel + 2 * B + 1);
+  SV v = {{a.x, a.y, a.z}, {b.x, b.y, b.z}};
+  return v;
+}
+template <int B>
+SSD void vel_put(const Lds& L, const SV& v) {
+  L.q(kLdsVel + 2 * B) = make_float4(v.w[0], v.w[1], v.w[2], 0.f);
+  L.q(kLdsVel + 2 * B + 1) = make_float4(v.v[0], v.v[1], v.v[2], 0.f);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // ABA impulse response restricted to what the contact stage needs.
 //   fR / fL : spatial impulses on the right / left foot (foot frame); LOAD_* says which are non-zero
 //   outputs : foot twists VR, VL; if FULL also dv0 and dqd[21] (whole tree, arms included)
 template <class Model, bool LOAD_R, bool LOAD_L, bool FULL>
-SSD void impulse_response(const JointCache& jc, const SV& fR, const SV& fL, SV& VR, SV& VL, SV* dv0, float* dqd) {
-  float ul[NJ];   // only leg + spine entries are ever non-zero
-  SV pPel;        // impulse bias accumulated at the pelvis (body 3)
-  bool pel_init = false;
+SSD void impulse_response(const JointCache& jc, const Lds& L, const SV& fR, const SV& fL, SV& VR, SV& VL, SV* dv0,
+                          float* dqd) {
+  float ul[kNumLegJoints];   // only loaded leg + spine entries are used
+  auto up = [&](auto Jc, const SV& p) {
+    constexpr int j = decltype(Jc)::value, ax = kAxis[j];
+    const JRec& r = jc.r[j];
+    float u = -p.w[ax];
+    ul[j] = u;
+    float du = r.Dinv * u;
+    SV pa;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { pa.w[i] = p.w[i] + r.Uw[i] * du; pa.v[i] = p.v[i] + r.Uv[i] * du; }
+    SV o = xforce<Model, j>(r.cs, r.sn, pa);
+    SS_FENCE();
+    return o;
+  };
   auto leg_up = [&](auto J0c, const SV& f) {
     constexpr int j0 = decltype(J0c)::value;
     SV p = {{-f.w[0], -f.w[1], -f.w[2]}, {-f.v[0], -f.v[1], -f.v[2]}};
-    static_rfor<j0 + 4, j0>([&](auto Jc) {
-      constexpr int j = decltype(Jc)::value, ax = kAxis[j];
-      float u = -p.w[ax];
-      ul[j] = u;
-      float du = jc.Dinv[j] * u;
-      SV pa;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { pa.w[i] = p.w[i] + jc.Uw[j][i] * du; pa.v[i] = p.v[i] + jc.Uv[j][i] * du; }
-      p = xforce<Model, j>(jc.cs[j], jc.sn[j], pa);
-    });
+    static_rfor<j0 + 4, j0>([&](auto Jc) { p = up(Jc, p); });
     return p;
   };
-  if constexpr (LOAD_R) { pPel = leg_up(std::integral_constant<int, 3>{}, fR); pel_init = true; }
+  SV pPel;
+  if constexpr (LOAD_R) pPel = leg_up(std::integral_constant<int, 3>{}, fR);
   if constexpr (LOAD_L) {
     SV t = leg_up(std::integral_constant<int, 8>{}, fL);
     if constexpr (LOAD_R) {
@@ -93,102 +161,98 @@ SSD void impulse_response(const JointCache& jc, const SV& fR, const SV& fL, SV& 
       pPel = t;
     }
   }
-  (void)pel_init;
-  // spine 2,1,0
   SV p = pPel;
-  static_rfor<2, 0>([&](auto Jc) {
-    constexpr int j = decltype(Jc)::value, ax = kAxis[j];
-    float u = -p.w[ax];
-    ul[j] = u;
-    float du = jc.Dinv[j] * u;
-    SV pa;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { pa.w[i] = p.w[i] + jc.Uw[j][i] * du; pa.v[i] = p.v[i] + jc.Uv[j][i] * du; }
-    p = xforce<Model, j>(jc.cs[j], jc.sn[j], pa);
-  });
+  static_rfor<2, 0>([&](auto Jc) { p = up(Jc, p); });
   SV d0 = chol6_solve_neg(jc.L0, p);
   if constexpr (FULL) *dv0 = d0;
-  // down
-  auto down = [&](auto Jc, const SV& dpar, bool) {
+  auto down = [&](auto Jc, const SV& dpar) {
     constexpr int j = decltype(Jc)::value, ax = kAxis[j];
     constexpr bool loaded = (j <= 2) || (LOAD_R && j >= 3 && j <= 7) || (LOAD_L && j >= 8 && j <= 12);
-    SV d = xmotion<Model, j>(jc.cs[j], jc.sn[j], dpar);
-    float dotv = jc.Uw[j][0] * d.w[0] + jc.Uw[j][1] * d.w[1] + jc.Uw[j][2] * d.w[2] + jc.Uv[j][0] * d.v[0] +
-                 jc.Uv[j][1] * d.v[1] + jc.Uv[j][2] * d.v[2];
+    const JRec r = jrec_get<j>(jc, L);
+    SV d = xmotion<Model, j>(r.cs, r.sn, dpar);
+    float dotv = r.Uw[0] * d.w[0] + r.Uw[1] * d.w[1] + r.Uw[2] * d.w[2] + r.Uv[0] * d.v[0] + r.Uv[1] * d.v[1] +
+                 r.Uv[2] * d.v[2];
     float dq;
-    if constexpr (loaded) dq = jc.Dinv[j] * (ul[j] - dotv);
-    else dq = -jc.Dinv[j] * dotv;
+    if constexpr (loaded) dq = r.Dinv * (ul[j] - dotv);
+    else dq = -r.Dinv * dotv;
     d.w[ax] += dq;
     if constexpr (FULL) dqd[j] = dq;
+    SS_FENCE();
     return d;
   };
-  SV d1 = down(std::integral_constant<int, 0>{}, d0, true);
-  SV d2 = down(std::integral_constant<int, 1>{}, d1, true);
-  SV d3 = down(std::integral_constant<int, 2>{}, d2, true);
+  SV d3 = down(std::integral_constant<int, 2>{}, down(std::integral_constant<int, 1>{}, down(std::integral_constant<int, 0>{}, d0)));
   {
-    SV a = down(std::integral_constant<int, 3>{}, d3, true);
-    a = down(std::integral_constant<int, 4>{}, a, true);
-    a = down(std::integral_constant<int, 5>{}, a, true);
-    a = down(std::integral_constant<int, 6>{}, a, true);
-    VR = down(std::integral_constant<int, 7>{}, a, true);
+    SV a = d3;
+    static_for<3, 8>([&](auto Jc) { a = down(Jc, a); });
+    VR = a;
   }
   {
-    SV a = down(std::integral_constant<int, 8>{}, d3, true);
-    a = down(std::integral_constant<int, 9>{}, a, true);
-    a = down(std::integral_constant<int, 10>{}, a, true);
-    a = down(std::integral_constant<int, 11>{}, a, true);
-    VL = down(std::integral_constant<int, 12>{}, a, true);
+    SV a = d3;
+    static_for<8, 13>([&](auto Jc) { a = down(Jc, a); });
+    VL = a;
   }
   if constexpr (FULL) {
-    SV a = down(std::integral_constant<int, 13>{}, d0, true);
-    a = down(std::integral_constant<int, 14>{}, a, true);
-    a = down(std::integral_constant<int, 15>{}, a, true);
-    a = down(std::integral_constant<int, 16>{}, a, true);
-    a = down(std::integral_constant<int, 17>{}, d0, true);
-    a = down(std::integral_constant<int, 18>{}, a, true);
-    a = down(std::integral_constant<int, 19>{}, a, true);
-    a = down(std::integral_constant<int, 20>{}, a, true);
-    (void)a;
+    SV a = d0;
+    static_for<13, 17>([&](auto Jc) { a = down(Jc, a); });
+    a = d0;
+    static_for<17, 21>([&](auto Jc) { a = down(Jc, a); });
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// power: torque scale; the clipped actions of this control step sit in LDS (kLdsAct)
 template <class Model>
-SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport& fr, float4* lds4, int lane) {
+SSD void substep(Dyn& s, float power, const Stones& st, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) sincosf(s.q[j], &jc.sn[j], &jc.cs[j]);
-
-  // ---- pass 1: velocities
-  SV vel[NB];
-  vel[0] = s.v0;
   static_for<0, NJ>([&](auto Jc) {
-    constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
-    vel[b] = xmotion<Model, j>(jc.cs[j], jc.sn[j], vel[p]);
-    vel[b].w[ax] += s.qd[j];
+    constexpr int j = decltype(Jc)::value;
+    float sn, cs;
+    sincosf(s.q[j], &sn, &cs);
+    if constexpr (j < kNumLegJoints) { jc.r[j].cs = cs; jc.r[j].sn = sn; }
+    else { L.flat(kLdsArms, (j - kNumLegJoints) * 10 + 0) = cs; L.flat(kLdsArms, (j - kNumLegJoints) * 10 + 1) = sn; }
   });
+
+  // ---- pass 1: velocities (kept in LDS; the chain predecessor stays in registers)
+  vel_put<0>(L, s.v0);
+  {
+    SV prev = s.v0;
+    static_for<0, NJ>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
+      float c, sn;
+      jcs_get<j>(jc, L, c, sn);
+      SV vp;
+      if constexpr (p == j) vp = prev;               // parent is the body processed just before
+      else if constexpr (p == 0) vp = s.v0;
+      else vp = vel_get<p>(L);
+      SV v = xmotion<Model, j>(c, sn, vp);
+      v.w[ax] += s.qd[j];
+      vel_put<b>(L, v);
+      prev = v;
+      SS_FENCE();
+    });
+  }
 
   // ---- pass 2: articulated inertias
   ABI acc[NB];
   SV pacc[NB];
-  float uu[NJ];
   static_rfor<NJ - 1, 0>([&](auto Jc) {
     constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
     constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
     constexpr bool leaf = first_child(b) < 0;
     constexpr bool massive = Model::mass[b] != 0.f;
+    const SV vb = vel_get<b>(L);
     ABI I;
     SV pA;
     if constexpr (leaf) {
       I = abi_body<Model, b>();
-      pA = body_bias<Model, b>(vel[b]);
+      pA = body_bias<Model, b>(vb);
     } else {
       I = acc[b];
       pA = pacc[b];
       if constexpr (massive) {
         abi_add_body<Model, b>(I);
-        SV pb = body_bias<Model, b>(vel[b]);
+        SV pb = body_bias<Model, b>(vb);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { pA.w[i] += pb.w[i]; pA.v[i] += pb.v[i]; }
       }
@@ -196,24 +260,27 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
     // joint torque (explicit part) and implicit diagonal, PHYSICS.md 3.1
     constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
     constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j];
+    constexpr float tq = Model::torque[j];
     float q = s.q[j], qd = s.qd[j];
     float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
     bool lim = viol != 0.f;
     float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
-    float tau = tau_m[j] - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
+    float tau_m = power * tq * L.flat(kLdsAct, j);
+    float tau = tau_m - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
     float Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
     // U = I S
-    float Uw[3] = {I.A.template get<0, ax>(), I.A.template get<1, ax>(), I.A.template get<2, ax>()};
-    float Uv[3] = {I.B[ax][0], I.B[ax][1], I.B[ax][2]};
-    float Dinv = 1.0f / (Uw[ax] + Dadd);
-    float u = tau - pA.w[ax];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { jc.Uw[j][i] = Uw[i]; jc.Uv[j][i] = Uv[i]; }
-    jc.Dinv[j] = Dinv;
-    uu[j] = u;
+    JRec r;
+    jcs_get<j>(jc, L, r.cs, r.sn);
+    r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
+    r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
+    r.Dinv = 1.0f / (r.Uw[ax] + Dadd);
+    r.u = tau - pA.w[ax];
+    jrec_put<j>(jc, L, r);
+    const float* Uw = r.Uw;
+    const float* Uv = r.Uv;
     // Ia = I - U Dinv U^T
-    float sw[3] = {Dinv * Uw[0], Dinv * Uw[1], Dinv * Uw[2]};
-    float sv[3] = {Dinv * Uv[0], Dinv * Uv[1], Dinv * Uv[2]};
+    float sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
+    float sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
     I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
     I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
     I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
@@ -223,22 +290,22 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
 #pragma unroll
       for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
     // c = v x S qd : only components ai, aj are non-zero
-    float cwi = qd * vel[b].w[aj], cwj = -qd * vel[b].w[ai];
-    float cvi = qd * vel[b].v[aj], cvj = -qd * vel[b].v[ai];
-    float du = Dinv * u;
+    float cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
+    float cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
+    float du = r.Dinv * r.u;
     SV pa;
     {
       const Sym3 &A = I.A, &C = I.C;
       float Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
       float Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        pa.w[r] = pA.w[r] + Af[r][ai] * cwi + Af[r][aj] * cwj + I.B[r][ai] * cvi + I.B[r][aj] * cvj + Uw[r] * du;
-        pa.v[r] = pA.v[r] + I.B[ai][r] * cwi + I.B[aj][r] * cwj + Cf[r][ai] * cvi + Cf[r][aj] * cvj + Uv[r] * du;
+      for (int rr = 0; rr < 3; ++rr) {
+        pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
+        pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
       }
     }
-    ABI Ip = xinertia<Model, j>(jc.cs[j], jc.sn[j], I);
-    SV pp = xforce<Model, j>(jc.cs[j], jc.sn[j], pa);
+    ABI Ip = xinertia<Model, j>(r.cs, r.sn, I);
+    SV pp = xforce<Model, j>(r.cs, r.sn, pa);
     if constexpr (b == first_child(p)) {
       acc[p] = Ip;
       pacc[p] = pp;
@@ -247,6 +314,7 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
 #pragma unroll
       for (int i = 0; i < 3; ++i) { pacc[p].w[i] += pp.w[i]; pacc[p].v[i] += pp.v[i]; }
     }
+    SS_FENCE();
   });
 
   // ---- base
@@ -254,7 +322,7 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
   {
     ABI I0 = acc[0];
     abi_add_body<Model, 0>(I0);
-    SV pb = body_bias<Model, 0>(vel[0]);
+    SV pb = body_bias<Model, 0>(s.v0);
     SV p0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { p0.w[i] = pacc[0].w[i] + pb.w[i]; p0.v[i] = pacc[0].v[i] + pb.v[i]; }
@@ -263,25 +331,35 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
     jc.L0 = chol6(M);
     a0 = chol6_solve_neg(jc.L0, p0);
   }
+  SS_FENCE();
 
   // ---- pass 3: accelerations -> free velocities
   float qdf[NJ];
   {
-    SV acl[NB];
-    acl[0] = a0;
+    SV prev = a0;
+    SV a3 = a0;   // acceleration of the pelvis (body 3), branch point of the legs
     static_for<0, NJ>([&](auto Jc) {
       constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-      SV a = xmotion<Model, j>(jc.cs[j], jc.sn[j], acl[p]);
+      const JRec r = jrec_get<j>(jc, L);
+      const SV vb = vel_get<b>(L);
+      SV ap;
+      if constexpr (p == j) ap = prev;
+      else if constexpr (p == 0) ap = a0;
+      else ap = a3;                                   // p == 3 is the only other branch point
+      static_assert(p == j || p == 0 || p == 3, "tree shape");
+      SV a = xmotion<Model, j>(r.cs, r.sn, ap);
       float qd = s.qd[j];
-      a.w[ai] += qd * vel[b].w[aj]; a.w[aj] -= qd * vel[b].w[ai];
-      a.v[ai] += qd * vel[b].v[aj]; a.v[aj] -= qd * vel[b].v[ai];
-      float dotv = jc.Uw[j][0] * a.w[0] + jc.Uw[j][1] * a.w[1] + jc.Uw[j][2] * a.w[2] + jc.Uv[j][0] * a.v[0] +
-                   jc.Uv[j][1] * a.v[1] + jc.Uv[j][2] * a.v[2];
-      float qdd = jc.Dinv[j] * (uu[j] - dotv);
+      a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
+      a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
+      float dotv = r.Uw[0] * a.w[0] + r.Uw[1] * a.w[1] + r.Uw[2] * a.w[2] + r.Uv[0] * a.v[0] + r.Uv[1] * a.v[1] +
+                   r.Uv[2] * a.v[2];
+      float qdd = r.Dinv * (r.u - dotv);
       a.w[ax] += qdd;
-      acl[b] = a;
+      if constexpr (b == 3) a3 = a;
+      prev = a;
       qdf[j] = qd + h * qdd;
+      SS_FENCE();
     });
   }
   float Rb[3][3];
@@ -307,7 +385,7 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
       constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       constexpr float rx = Model::r[j][0], ry = Model::r[j][1], rz = Model::r[j][2];
-      float c = jc.cs[j], sn = jc.sn[j];
+      float c = jc.r[j].cs, sn = jc.r[j].sn;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         float o = pw[p][r];
@@ -325,9 +403,10 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
       for (int c = 0; c < 3; ++c) { Rf[0][a][c] = Rw[RFOOT][a][c]; Rf[1][a][c] = Rw[LFOOT][a][c]; }
     }
   }
+  SS_FENCE();
   int active = 0;          // bit k
+  int cslot = 0;           // 2 bits per contact: stone slot
   float pen[8];
-  float cn[8][3];          // contact normal (world)
   fr.contact = 0;
   fr.on_target = 0;
   static_for<0, 2>([&](auto Fc) {
@@ -344,20 +423,19 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
       }
       float best = 0.f;
       int slot = -1;
-      float bn[3] = {0.f, 0.f, 1.f};
 #pragma unroll
       for (int sl = 0; sl < 3; ++sl) {
         float dx = P[0] - st.p[sl][0], dy = P[1] - st.p[sl][1], dz = P[2] - st.p[sl][2];
-        float d = dx * st.n[sl][0] + dy * st.n[sl][1] + dz * st.n[sl][2];
-        float lx = dx - d * st.n[sl][0], ly = dy - d * st.n[sl][1], lz = dz - d * st.n[sl][2];
+        float d = dx * st.nrm[sl][0] + dy * st.nrm[sl][1] + dz * st.nrm[sl][2];
+        float lx = dx - d * st.nrm[sl][0], ly = dy - d * st.nrm[sl][1], lz = dz - d * st.nrm[sl][2];
         float rho2 = lx * lx + ly * ly + lz * lz;
         bool hit = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2) && (d < best);
-        if (hit) { best = d; slot = sl; bn[0] = st.n[sl][0]; bn[1] = st.n[sl][1]; bn[2] = st.n[sl][2]; }
+        if (hit) { best = d; slot = sl; }
       }
       pen[ck] = -best;
-      cn[ck][0] = bn[0]; cn[ck][1] = bn[1]; cn[ck][2] = bn[2];
       if (slot >= 0) {
         active |= 1 << ck;
+        cslot |= slot << (2 * ck);
         fr.contact |= 1 << f;
         if (slot == 1) fr.on_target |= 1 << f;
       }
@@ -380,10 +458,10 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
 #pragma unroll
       for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? 1.f : 0.f; e.v[m] = (i == m + 3) ? 1.f : 0.f; }
       SV VR, VL;
-      impulse_response<Model, true, false, false>(jc, e, zero, VR, VL, nullptr, nullptr);
-      LDS4(kLdsLinv + i * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
-      LDS4(kLdsLinv + i * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
-      LDS4(kLdsLinv + i * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+      impulse_response<Model, true, false, false>(jc, L, e, zero, VR, VL, nullptr, nullptr);
+      L.q(kLdsLinv + i * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
+      L.q(kLdsLinv + i * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
+      L.q(kLdsLinv + i * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
     }
 #pragma unroll 1
     for (int i = 0; i < 6; ++i) {
@@ -391,40 +469,51 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
 #pragma unroll
       for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? 1.f : 0.f; e.v[m] = (i == m + 3) ? 1.f : 0.f; }
       SV VR, VL;
-      impulse_response<Model, false, true, false>(jc, zero, e, VR, VL, nullptr, nullptr);
-      LDS4(kLdsLinv + (6 + i) * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
-      LDS4(kLdsLinv + (6 + i) * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
-      LDS4(kLdsLinv + (6 + i) * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+      impulse_response<Model, false, true, false>(jc, L, zero, e, VR, VL, nullptr, nullptr);
+      L.q(kLdsLinv + (6 + i) * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
+      L.q(kLdsLinv + (6 + i) * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
+      L.q(kLdsLinv + (6 + i) * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
     }
     // foot twists under the free velocities
     float V[12];
     {
-      SV vb[14];
-      vb[0] = v0f;
-      static_for<0, 13>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
-        vb[b] = xmotion<Model, j>(jc.cs[j], jc.sn[j], vb[p]);
-        vb[b].w[ax] += qdf[j];
+      SV a = v0f;
+      static_for<0, 3>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        a = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, a);
+        a.w[kAxis[j]] += qdf[j];
+      });
+      SV b = a;
+      static_for<3, 8>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        a = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, a);
+        a.w[kAxis[j]] += qdf[j];
+      });
+      static_for<8, 13>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        b = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, b);
+        b.w[kAxis[j]] += qdf[j];
       });
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        V[i] = vb[RFOOT].w[i]; V[3 + i] = vb[RFOOT].v[i];
-        V[6 + i] = vb[LFOOT].w[i]; V[9 + i] = vb[LFOOT].v[i];
-      }
+      for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; V[6 + i] = b.w[i]; V[9 + i] = b.v[i]; }
     }
+    SS_FENCE();
     // rows -> LDS
     static_for<0, 8>([&](auto Kc) {
       constexpr int ck = decltype(Kc)::value, f = ck / 4, k = ck % 4;
       if (active & (1 << ck)) {
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-        float n[3] = {cn[ck][0], cn[ck][1], cn[ck][2]};
+        const int sl = (cslot >> (2 * ck)) & 3;
+        float n[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) n[i] = sl == 0 ? st.nrm[0][i] : (sl == 1 ? st.nrm[1][i] : st.nrm[2][i]);
         float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
         float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
         t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
         float t2[3];
         cross(n, t1, t2);
         float corr = fmaxf(pen[ck] - kSlop, 0.f);
-        float bnv = fminf(kErp * corr * (1.0f / kH), kVcorrMax);
+        L.flat(kLdsBn, ck) = fminf(kErp * corr * (1.0f / kH), kVcorrMax);
         static_for<0, 3>([&](auto Dc) {
           constexpr int d = decltype(Dc)::value;
           const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
@@ -441,9 +530,9 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
           for (int o = 0; o < 12; ++o) y[o] = 0.f;
 #pragma unroll
           for (int l = 0; l < 6; ++l) {
-            float4 c0 = LDS4(kLdsLinv + (f * 6 + l) * 3 + 0);
-            float4 c1 = LDS4(kLdsLinv + (f * 6 + l) * 3 + 1);
-            float4 c2 = LDS4(kLdsLinv + (f * 6 + l) * 3 + 2);
+            float4 c0 = L.q(kLdsLinv + (f * 6 + l) * 3 + 0);
+            float4 c1 = L.q(kLdsLinv + (f * 6 + l) * 3 + 1);
+            float4 c2 = L.q(kLdsLinv + (f * 6 + l) * 3 + 2);
             y[0] += c0.x * w[l]; y[1] += c0.y * w[l]; y[2] += c0.z * w[l]; y[3] += c0.w * w[l];
             y[4] += c1.x * w[l]; y[5] += c1.y * w[l]; y[6] += c1.z * w[l]; y[7] += c1.w * w[l];
             y[8] += c2.x * w[l]; y[9] += c2.y * w[l]; y[10] += c2.z * w[l]; y[11] += c2.w * w[l];
@@ -451,14 +540,14 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
           float A = 0.f;
 #pragma unroll
           for (int l = 0; l < 6; ++l) A += w[l] * y[f * 6 + l];
-          constexpr int row = kLdsRows + (ck * 3 + d) * 5;
-          LDS4(row + 0) = make_float4(y[0], y[1], y[2], y[3]);
-          LDS4(row + 1) = make_float4(y[4], y[5], y[6], y[7]);
-          LDS4(row + 2) = make_float4(y[8], y[9], y[10], y[11]);
-          LDS4(row + 3) = make_float4(w[0], w[1], w[2], w[3]);
-          LDS4(row + 4) = make_float4(w[4], w[5], 1.0f / A, d == 0 ? bnv : 0.f);
+          constexpr int row = kLdsRows + (ck * 3 + d) * 4;
+          L.q(row + 0) = make_float4(y[0], y[1], y[2], y[3]);
+          L.q(row + 1) = make_float4(y[4], y[5], y[6], y[7]);
+          L.q(row + 2) = make_float4(y[8], y[9], y[10], y[11]);
+          L.q(row + 3) = make_float4(w[3], w[4], w[5], 1.0f / A);
         });
       }
+      SS_FENCE();
     });
     // projected Gauss-Seidel
     float lam[8][3];
@@ -468,15 +557,23 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
 #pragma unroll 1
     for (int it = 0; it < kPgsIters; ++it) {
       static_for<0, 8>([&](auto Kc) {
-        constexpr int ck = decltype(Kc)::value, f = ck / 4;
+        constexpr int ck = decltype(Kc)::value, f = ck / 4, k = ck % 4;
+        constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
         if (active & (1 << ck)) {
+          const float bn = L.flat(kLdsBn, ck);
           static_for<0, 3>([&](auto Dc) {
             constexpr int d = decltype(Dc)::value;
-            constexpr int row = kLdsRows + (ck * 3 + d) * 5;
-            float4 y0 = LDS4(row + 0), y1 = LDS4(row + 1), y2 = LDS4(row + 2), w0 = LDS4(row + 3), w1 = LDS4(row + 4);
-            float vrel = w0.x * V[f * 6 + 0] + w0.y * V[f * 6 + 1] + w0.z * V[f * 6 + 2] + w0.w * V[f * 6 + 3] +
-                         w1.x * V[f * 6 + 4] + w1.y * V[f * 6 + 5];
-            float ln = lam[ck][d] + (w1.w - vrel) * w1.z;
+            constexpr int row = kLdsRows + (ck * 3 + d) * 4;
+            float4 y0 = L.q(row + 0), y1 = L.q(row + 1), y2 = L.q(row + 2), w1 = L.q(row + 3);
+            // velocity of the corner: v + w x r, projected on the row direction
+            const float* Vw = V + f * 6;
+            const float* Vv = V + f * 6 + 3;
+            float px = Vv[0] + Vw[1] * cz - Vw[2] * cy;
+            float py = Vv[1] + Vw[2] * cx - Vw[0] * cz;
+            float pz = Vv[2] + Vw[0] * cy - Vw[1] * cx;
+            float vrel = w1.x * px + w1.y * py + w1.z * pz;
+            float target = d == 0 ? bn : 0.f;
+            float ln = lam[ck][d] + (target - vrel) * w1.w;
             if constexpr (d == 0) {
               ln = fmaxf(ln, 0.f);
             } else {
@@ -495,21 +592,25 @@ SSD void substep(Dyn& s, const float (&tau_m)[NJ], const Stones& st, FootReport&
     // accumulated foot wrenches -> whole tree
     SV WR = zero, WL = zero;
     static_for<0, 8>([&](auto Kc) {
-      constexpr int ck = decltype(Kc)::value, f = ck / 4;
+      constexpr int ck = decltype(Kc)::value, f = ck / 4, k = ck % 4;
+      constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
       if (active & (1 << ck)) {
+        // total contact force at this corner (foot frame), then its moment about the foot origin
+        float fx = 0.f, fy = 0.f, fz = 0.f;
         static_for<0, 3>([&](auto Dc) {
           constexpr int d = decltype(Dc)::value;
-          constexpr int row = kLdsRows + (ck * 3 + d) * 5;
-          float4 w0 = LDS4(row + 3), w1 = LDS4(row + 4);
-          float l = lam[ck][d];
-          SV& W = f == 0 ? WR : WL;
-          W.w[0] += w0.x * l; W.w[1] += w0.y * l; W.w[2] += w0.z * l;
-          W.v[0] += w0.w * l; W.v[1] += w1.x * l; W.v[2] += w1.y * l;
+          float4 w1 = L.q(kLdsRows + (ck * 3 + d) * 4 + 3);
+          fx += w1.x * lam[ck][d]; fy += w1.y * lam[ck][d]; fz += w1.z * lam[ck][d];
         });
+        SV& W = f == 0 ? WR : WL;
+        W.v[0] += fx; W.v[1] += fy; W.v[2] += fz;
+        W.w[0] += cy * fz - cz * fy;
+        W.w[1] += cz * fx - cx * fz;
+        W.w[2] += cx * fy - cy * fx;
       }
     });
     SV VR, VL;
-    impulse_response<Model, true, true, true>(jc, WR, WL, VR, VL, &dv0, dqd);
+    impulse_response<Model, true, true, true>(jc, L, WR, WL, VR, VL, &dv0, dqd);
   }
 
   // ---- integrate (semi-implicit Euler)

@@ -34,9 +34,7 @@ struct Params {
   int auto_reset;
 };
 
-struct Cache {           // active stones n-1, n, n+1: centre, normal, tilts
-  float p[3][3], nrm[3][3], tilt[3][2];
-};
+using Cache = Stones;    // active stones n-1, n, n+1: centre, normal, tilts (ss_dynamics.hpp)
 
 SSD float yaw_sample(int i) { return (-20.0f + 4.0f * (float)i) * kDeg; }
 SSD float pitch_sample(int j) { return (-30.0f + 6.0f * (float)j) * kDeg; }
@@ -282,33 +280,24 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4
   int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
   uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
 
-  // 1. action -> motor torques
-  float a[NJ], tau[NJ];
+  // 1. clipped actions -> LDS (read by every substep's pass 2 and by the reward)
+  const Lds L{lds4, lane};
   if constexpr (RANDOM_ACT) {
     uint32_t r[6][4];
 #pragma unroll
     for (int b = 0; b < 6; ++b)
       philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r[b]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) a[j] = 2.f * u01(r[j / 4][j % 4]) - 1.f;
+    for (int j = 0; j < NJ; ++j) L.flat(kLdsAct, j) = 2.f * u01(r[j / 4][j % 4]) - 1.f;
   } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) a[j] = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
+    for (int j = 0; j < NJ; ++j) L.flat(kLdsAct, j) = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
   }
-  static_for<0, NJ>([&](auto Jc) {
-    constexpr int j = decltype(Jc)::value;
-    tau[j] = P.power * Model::torque[j] * a[j];
-  });
 
   // 2. four substeps
-  Stones st;
-#pragma unroll
-  for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { st.p[sl][i] = c.p[sl][i]; st.n[sl][i] = c.nrm[sl][i]; }
   FootReport fr;
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) substep<Model>(s, tau, st, fr, lds4, lane);
+  for (int k = 0; k < 4; ++k) substep<Model>(s, P.power, c, fr, L);
 
   // 3-4
   elapsed += 1;
@@ -371,8 +360,9 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4
     constexpr int j = decltype(Jc)::value;
     constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
     constexpr float span = Model::hi[j] - Model::lo[j];
-    e_sum += fabsf(a[j] * (0.1f * s.qd[j]));
-    a2 += a[j] * a[j];
+    const float aj = L.flat(kLdsAct, j);
+    e_sum += fabsf(aj * (0.1f * s.qd[j]));
+    a2 += aj * aj;
     if (fabsf(2.f * (s.q[j] - mid) / span) > 0.99f) at_limit += 1;
   });
   float energy = (4.5f / NJ) * (e_sum / NJ) + (0.225f / NJ) * (a2 / NJ);
