@@ -266,7 +266,7 @@ struct StepIO {
 
 // one control step of env e_raw (lane-private LDS column `lane` of lds4); PHYSICS.md section 4
 template <class Model, bool RANDOM_ACT>
-SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4* lds4) {
+SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float* lds) {
   const bool valid = e_raw < P.n;
   const int e = valid ? e_raw : P.n - 1;
   const size_t np = (size_t)P.npad;
@@ -281,23 +281,25 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4
   uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
 
   // 1. clipped actions -> LDS (read by every substep's pass 2 and by the reward)
-  const Lds L{lds4, lane};
+  const Lds L{lds, lane};
   if constexpr (RANDOM_ACT) {
     uint32_t r[6][4];
 #pragma unroll
     for (int b = 0; b < 6; ++b)
       philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r[b]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) L.flat(kLdsAct, j) = 2.f * u01(r[j / 4][j % 4]) - 1.f;
+    for (int j = 0; j < NJ; ++j) L.s(S_ACT + j) = 2.f * u01(r[j / 4][j % 4]) - 1.f;
   } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) L.flat(kLdsAct, j) = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
+    for (int j = 0; j < NJ; ++j) L.s(S_ACT + j) = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
   }
 
-  // 2. four substeps
+  // 2. four substeps on the LDS-resident state
+  dyn_to_lds(s, c, L);
   FootReport fr;
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) substep<Model>(s, P.power, c, fr, L);
+  for (int k = 0; k < 4; ++k) substep<Model>(P.power, fr, L);
+  dyn_from_lds(s, L);
 
   // 3-4
   elapsed += 1;
@@ -360,7 +362,7 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4
     constexpr int j = decltype(Jc)::value;
     constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
     constexpr float span = Model::hi[j] - Model::lo[j];
-    const float aj = L.flat(kLdsAct, j);
+    const float aj = L.s(S_ACT + j);
     e_sum += fabsf(aj * (0.1f * s.qd[j]));
     a2 += aj * aj;
     if (fabsf(2.f * (s.q[j] - mid) / span) > 0.99f) at_limit += 1;
@@ -407,7 +409,7 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float4
 template <class Model, bool RANDOM_ACT>
 __global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
   __shared__ float4 lds4[kLdsSlots * kWave];
-  step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, lds4);
+  step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, reinterpret_cast<float*>(lds4));
 }
 #endif  // SS_HOST_HARNESS
 

@@ -44,8 +44,8 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   ss::StepIO io{act, obs, rew, done, info, 0};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
   for (int e = 0; e < n; ++e) {
-    if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, e, e % 64, lds.data());
-    else ss::step_env<ss::ModelMike, false>(P, io, e, e % 64, lds.data());
+    if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, e, e % 64, reinterpret_cast<float*>(lds.data()));
+    else ss::step_env<ss::ModelMike, false>(P, io, e, e % 64, reinterpret_cast<float*>(lds.data()));
   }
   for (int e = 0; e < n; ++e) ss::pack_env(P, e, packed_out);
   return 0;
