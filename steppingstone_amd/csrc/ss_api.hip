@@ -132,6 +132,7 @@ void ss_destroy(ss_env* env) {
   if (env->P.terrain) (void)hipFree(env->P.terrain);
   if (env->prob_shared) (void)hipFree(env->prob_shared);
   if (env->prob_env) (void)hipFree(env->prob_env);
+  if (env->P.prof) (void)hipFree(env->P.prof);
   delete env;
 }
 
@@ -253,6 +254,20 @@ int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens) {
     lens[i] = (int32_t)lists[i]->size();
     for (int32_t v : *lists[i]) *o++ = v;
   }
+  return SS_OK;
+}
+
+// tuning aid: per-phase shader-clock totals (all zeros unless the library was built with -DSS_PROFILE_PHASES)
+int ss_debug_phase_cycles(ss_env* env, unsigned long long* out16, int reset) {
+  if (!env || !out16) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
+  if (!env->P.prof) {
+    SS_HIP(hipMalloc(&env->P.prof, 16 * sizeof(unsigned long long)));
+    SS_HIP(hipMemset(env->P.prof, 0, 16 * sizeof(unsigned long long)));
+  }
+  SS_HIP(hipDeviceSynchronize());
+  SS_HIP(hipMemcpy(out16, env->P.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) SS_HIP(hipMemset(env->P.prof, 0, 16 * sizeof(unsigned long long)));
   return SS_OK;
 }
 

@@ -50,6 +50,19 @@ constexpr int kNumLegJoints = 13;      // joints 0..12 (spine + legs) keep their
 #define SS_MEMBAR() asm volatile("" ::: "memory")
 #endif
 
+// optional per-phase cycle accounting (-DSS_PROFILE_PHASES; tuning builds only)
+#if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+struct Prof { uint32_t t[16]; uint32_t last; };
+#define SS_PROF_DECL Prof& prof,
+#define SS_PROF_ARG prof,
+#define SS_PROF(i) do { uint32_t _n = (uint32_t)__builtin_amdgcn_s_memtime(); prof.t[i] += _n - prof.last; prof.last = _n; } while (0)
+#else
+struct Prof { int unused; };
+#define SS_PROF_DECL
+#define SS_PROF_ARG
+#define SS_PROF(i) ((void)0)
+#endif
+
 struct Lds {       // lane-private view of the workgroup's LDS
   float* base;
   int lane;
@@ -224,9 +237,10 @@ SSD void impulse_response(const JointCache& jc, const Lds& L, const SV& fR, cons
 // ---------------------------------------------------------------------------------------------------------------
 // State (q, qd, base pose/twist), stones and clipped actions live in LDS (region B); power: torque scale.
 template <class Model>
-SSD void substep(float power, FootReport& fr, const Lds& L) {
+SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
+  SS_PROF(0);
   static_for<0, NJ>([&](auto Jc) {
     constexpr int j = decltype(Jc)::value;
     float sn, cs;
@@ -235,6 +249,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     else { L.s(S_ARMS + (j - kNumLegJoints) * 10 + 0) = cs; L.s(S_ARMS + (j - kNumLegJoints) * 10 + 1) = sn; }
   });
   SS_MEMBAR();
+  SS_PROF(1);
 
   // ---- pass 1: velocities (kept in LDS; the chain predecessor stays in registers)
   {
@@ -256,6 +271,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     });
   }
   SS_MEMBAR();
+  SS_PROF(2);
 
   // ---- pass 2: articulated inertias
   ABI acc[NB];
@@ -341,6 +357,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     SS_FENCE();
   });
 
+  SS_PROF(3);
   // ---- base
   SV a0;
   {
@@ -357,6 +374,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     a0 = chol6_solve_neg(jc.L0, p0);
   }
   SS_MEMBAR();
+  SS_PROF(4);
 
   // ---- pass 3: accelerations -> free velocities (to LDS)
   {
@@ -399,6 +417,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     }
   }
   SS_MEMBAR();
+  SS_PROF(5);
 
   // ---- detect: FK of spine + legs, sole corners vs stones
   float Rf[2][3][3], pf[2][3];
@@ -477,6 +496,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     });
   }
 
+  SS_PROF(6);
   // ---- contact solve
   float dqd[NJ];
   SV dv0;
@@ -487,6 +507,47 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
   if (active != 0) {
     // Lambda^-1 blocks -> LDS.  Column i of an R impulse holds [RR(:,i) ; LR(:,i)], of an L impulse [ - ; LL(:,i)].
     SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+// measured round 1 (4096 envs, ms/step): chains 1/2/4 with branchy PGS 0.283/0.295/-, branch-free PGS 0.318/0.325/0.315
+#ifndef SS_LINV_CHAINS
+#define SS_LINV_CHAINS 1
+#endif
+    auto put_r = [&](int col, const SV& VR, const SV& VL) {
+      L.q4(kLdsLinv + col * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
+      L.q4(kLdsLinv + col * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
+      L.q4(kLdsLinv + col * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+    };
+    auto put_l = [&](int col, const SV& VL) {
+      L.q4(kLdsLinv + (6 + col) * 3 + 1) = make_float4(0.f, 0.f, VL.w[0], VL.w[1]);
+      L.q4(kLdsLinv + (6 + col) * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+    };
+#if SS_LINV_CHAINS == 4
+    // four independent chains per iteration (R/L impulse x angular/linear component) so that the dependent
+    // up/solve/down recursions of one chain hide the latency of the others
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+      SV ea, eb;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { ea.w[m] = (i == m) ? 1.f : 0.f; ea.v[m] = 0.f; eb.w[m] = 0.f; eb.v[m] = (i == m) ? 1.f : 0.f; }
+      SV VRa, VLa, VRb, VLb, VRc, VLc, VRd, VLd;
+      impulse_response<Model, true, false, true, false>(jc, L, ea, zero, VRa, VLa, nullptr, nullptr);
+      impulse_response<Model, true, false, true, false>(jc, L, eb, zero, VRb, VLb, nullptr, nullptr);
+      impulse_response<Model, false, true, false, false>(jc, L, zero, ea, VRc, VLc, nullptr, nullptr);
+      impulse_response<Model, false, true, false, false>(jc, L, zero, eb, VRd, VLd, nullptr, nullptr);
+      put_r(i, VRa, VLa); put_r(3 + i, VRb, VLb); put_l(i, VLc); put_l(3 + i, VLd);
+    }
+#elif SS_LINV_CHAINS == 2
+    // two independent chains per iteration (right-foot and left-foot unit impulse)
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+      SV e;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? 1.f : 0.f; e.v[m] = (i == m + 3) ? 1.f : 0.f; }
+      SV VRa, VLa, VRc, VLc;
+      impulse_response<Model, true, false, true, false>(jc, L, e, zero, VRa, VLa, nullptr, nullptr);
+      impulse_response<Model, false, true, false, false>(jc, L, zero, e, VRc, VLc, nullptr, nullptr);
+      put_r(i, VRa, VLa); put_l(i, VLc);
+    }
+#else
 #pragma unroll 1
     for (int i = 0; i < 6; ++i) {
       SV e;
@@ -494,9 +555,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
       for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? 1.f : 0.f; e.v[m] = (i == m + 3) ? 1.f : 0.f; }
       SV VR, VL;
       impulse_response<Model, true, false, true, false>(jc, L, e, zero, VR, VL, nullptr, nullptr);
-      L.q4(kLdsLinv + i * 3 + 0) = make_float4(VR.w[0], VR.w[1], VR.w[2], VR.v[0]);
-      L.q4(kLdsLinv + i * 3 + 1) = make_float4(VR.v[1], VR.v[2], VL.w[0], VL.w[1]);
-      L.q4(kLdsLinv + i * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+      put_r(i, VR, VL);
     }
 #pragma unroll 1
     for (int i = 0; i < 6; ++i) {
@@ -505,9 +564,10 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
       for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? 1.f : 0.f; e.v[m] = (i == m + 3) ? 1.f : 0.f; }
       SV VR, VL;
       impulse_response<Model, false, true, false, false>(jc, L, zero, e, VR, VL, nullptr, nullptr);
-      L.q4(kLdsLinv + (6 + i) * 3 + 1) = make_float4(0.f, 0.f, VL.w[0], VL.w[1]);
-      L.q4(kLdsLinv + (6 + i) * 3 + 2) = make_float4(VL.w[2], VL.v[0], VL.v[1], VL.v[2]);
+      put_l(i, VL);
     }
+#endif
+    SS_PROF(7);
     // foot twists under the free velocities
     float V[12];
     {
@@ -581,8 +641,13 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
           L.q4(row + 1) = make_float4(y[4], y[5], w[3], w[4]);
           L.q4(row + 2) = make_float4(w[5], 1.0f / A, d == 0 ? bnv : 0.f, 0.f);
         });
+      } else {   // inactive contact: all-zero rows make every PGS update a no-op, so the sweeps stay branch-free
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) L.q4(kLdsRows + ck * 9 + i) = z;
       }
     });
+    SS_PROF(8);
     // projected Gauss-Seidel.  Rows of foot f only read V_f, so the effect of foot f's impulses on the other
     // foot's twist is applied once per sweep of foot f (exactly equivalent to updating it row by row).
     float lam[8][3];
@@ -594,14 +659,20 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     for (int it = 0; it < kPgsIters; ++it) {
       static_for<0, 2>([&](auto Fc) {
         constexpr int f = decltype(Fc)::value;
-        if ((active >> (4 * f)) & 15) {
+#ifndef SS_PGS_BRANCHFREE
+        if ((active >> (4 * f)) & 15)
+#endif
+        {
           SV dW = zero;
           float* Vw = V + f * 6;
           float* Vv = V + f * 6 + 3;
           static_for<0, 4>([&](auto Kc) {
             constexpr int k = decltype(Kc)::value, ck = f * 4 + k;
             constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-            if (active & (1 << ck)) {
+#ifndef SS_PGS_BRANCHFREE
+            if (active & (1 << ck))
+#endif
+            {
               float fc[3] = {0.f, 0.f, 0.f};
               static_for<0, 3>([&](auto Dc) {
                 constexpr int d = decltype(Dc)::value;
@@ -648,11 +719,13 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
         }
       });
     }
+    SS_PROF(9);
     // accumulated foot wrenches -> whole tree
     SV VR, VL;
     impulse_response<Model, true, true, true, true>(jc, L, W[0], W[1], VR, VL, &dv0, dqd);
   }
   SS_MEMBAR();
+  SS_PROF(10);
 
   // ---- integrate (semi-implicit Euler), state back to LDS
 #pragma unroll
@@ -680,6 +753,7 @@ SSD void substep(float power, FootReport& fr, const Lds& L) {
     L.s(S_QUAT) = nw * inv; L.s(S_QUAT + 1) = nx * inv; L.s(S_QUAT + 2) = ny * inv; L.s(S_QUAT + 3) = nz * inv;
   }
   SS_MEMBAR();
+  SS_PROF(11);
 }
 
 // move the control-step state between registers and its LDS home

@@ -32,6 +32,7 @@ struct Params {
   int curriculum;
   float power;
   int auto_reset;
+  unsigned long long* prof;   // 16 phase counters, tuning builds (-DSS_PROFILE_PHASES) only
 };
 
 using Cache = Stones;    // active stones n-1, n, n+1: centre, normal, tilts (ss_dynamics.hpp)
@@ -297,8 +298,15 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
   // 2. four substeps on the LDS-resident state
   dyn_to_lds(s, c, L);
   FootReport fr;
+#if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+  Prof prof;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) prof.t[i] = 0;
+  prof.last = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) substep<Model>(P.power, fr, L);
+  for (int k = 0; k < 4; ++k) substep<Model>(SS_PROF_ARG P.power, fr, L);
+  SS_PROF(12);
   dyn_from_lds(s, L);
 
   // 3-4
@@ -403,6 +411,11 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
     P.istate[e + I_RNG * np] = (int)ctr;
     P.istate[e + I_FLAGS * np] = flags;
   }
+#if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+  SS_PROF(13);
+  if (lane == 0 && P.prof)
+    for (int i = 0; i < 16; ++i) atomicAdd(P.prof + i, (unsigned long long)prof.t[i]);
+#endif
 }
 
 #ifndef SS_HOST_HARNESS

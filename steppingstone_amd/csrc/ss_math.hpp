@@ -18,8 +18,10 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 // optional scheduling fence between links of the unrolled tree sweeps (-DSS_SCHED_FENCE): measured round 1, it
 // lowers spills slightly (1325 -> 1193) but costs 4 % of step time, so it is off by default
-#ifdef SS_SCHED_FENCE
+#if defined(SS_SCHED_FENCE)
 #define SS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#elif defined(SS_MEM_FENCE)
+#define SS_FENCE() asm volatile("" ::: "memory")
 #else
 #define SS_FENCE() ((void)0)
 #endif

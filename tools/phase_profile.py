@@ -1,0 +1,28 @@
+"""Per-phase shader-clock breakdown of the step kernel.  Needs a library built with -DSS_PROFILE_PHASES:
+   hipcc <FLAGS> -DSS_PROFILE_PHASES csrc/ss_api.hip -o lib/libss_prof.so ; STEPPINGSTONE_LIB=.../libss_prof.so python tools/phase_profile.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from steppingstone_amd import _lib
+from steppingstone_amd.envs import SteppingStoneVecEnv
+NAMES = ["loop/entry", "sincos", "pass1 vel", "pass2 ABI", "base chol", "pass3 acc", "detect FK", "Linv 12 cols",
+         "Vfree+rows", "PGS x8", "final resp", "integrate", "after loop", "reward/obs/store", "", ""]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = 200
+env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=0, device="cuda:0")
+env.reset()
+lib = _lib.load()
+lib.ss_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+out = np.zeros(16, np.uint64)
+env.rollout_random(50, 0)
+lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
+env.rollout_random(steps, 50)
+lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
+waves = (n + 63) // 64
+per = out.astype(np.float64) / (waves * steps)
+tot = per.sum()
+print("cycles per wave per control step: %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400.0))
+for nm, v in zip(NAMES, per):
+    if nm:
+        print("  %-18s %9.0f  %5.1f %%" % (nm, v, 100 * v / tot))
