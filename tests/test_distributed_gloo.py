@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size-2 gloo, one process per 'GPU', each rank owning a contiguous block of envs (oracle-
+backed test double), per-step all-gather of the packed [obs|rew|done] block.  The gathered result must equal a
+single-process run over all envs (global env ids key the RNG, so sharding is invisible).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_LOCAL, WORLD, STEPS = 6, 2, 12
+
+
+def _worker(rank, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from oracle_backend import OracleBackend
+    from steppingstone_amd.distributed import ShardedVecEnv
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    local = SteppingStoneVecEnv("Walker3DStepperEnv-v0", N_LOCAL, seed=5, return_numpy=False, env_id_offset=rank * N_LOCAL,
+                                backend=OracleBackend(0, N_LOCAL, 5, env_id_offset=rank * N_LOCAL))
+    env = ShardedVecEnv(local)
+    assert env.num_envs == N_LOCAL * WORLD
+    out = [env.reset().clone().numpy()]
+    gen = torch.Generator().manual_seed(0)
+    for t in range(STEPS):
+        acts = torch.rand((env.num_envs, 21), generator=gen) * 2 - 1       # same global actions on every rank
+        obs, rew, done, _ = env.step(acts)
+        out.append(np.concatenate([obs.numpy(), rew.numpy()[:, None], done.numpy()[:, None].astype(np.float32)], 1))
+    # benchmark path too
+    o2, r2, d2 = env.rollout_random(2, t0=100)
+    out.append(np.concatenate([o2.numpy(), r2.numpy()[:, None], d2.numpy()[:, None].astype(np.float32)], 1))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_single_process():
+    import oracle_lib as ol
+    port = 29500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(port, ret), nprocs=WORLD, join=True)
+        res = {k: v for k, v in ret.items()}
+    o = ol.OracleEnv("walker3d", N_LOCAL * WORLD, seed=5)
+    ref = [o.reset()]
+    gen = torch.Generator().manual_seed(0)
+    for t in range(STEPS):
+        acts = (torch.rand((N_LOCAL * WORLD, 21), generator=gen) * 2 - 1).numpy()
+        ob, r, d, _ = o.step(acts)
+        ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
+    for k in range(2):
+        ob, r, d, _ = o.step(o.random_actions(100 + k))
+    ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
+    for rank in range(WORLD):
+        assert len(res[rank]) == len(ref)
+        for a, b in zip(res[rank], ref):
+            assert np.array_equal(a, b)
