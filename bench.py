@@ -30,6 +30,18 @@ ALGO_BYTES_PER_ENV_STEP = 348 + 521
 HBM_PEAK_GBS = 8000.0
 
 
+def recorded_traffic(n_envs):
+    """HBM bytes per step_kernel launch from the latest committed PMC run (separate FETCH_SIZE / WRITE_SIZE passes,
+    calibrated on a dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py).  PMC collection needs
+    rocprofv3 around the process, so bench.py reports the recorded figure and names its source; null if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic_%d.json" % n_envs)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The CPU oracle (a port of docs/PHYSICS.md, NOT PyBullet) on the host cores, same workload, bounded."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -120,6 +132,7 @@ def main():
         total_envs = n_local * world
         value = total_envs * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = recorded_traffic(n_local)
         out = {
             "metric": "env-steps/sec (batched random-action rollout)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -129,7 +142,8 @@ def main():
                                    "actions, auto-reset on" % (args.env, n_local, args.curriculum),
                        "envs_total": total_envs, "parallelism": "env-shard x%d%s" % (world, "+allgather" if gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "ss::step_kernel<ModelWalker3D,true>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
                          "note": "latency/VALU-bound per-lane rigid-body dynamics, not HBM-bound (DESIGN.md)"},

@@ -257,6 +257,15 @@ int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens) {
   return SS_OK;
 }
 
+// PMC calibration helper: copies n floats in -> out (dword per lane, coalesced), device pointers
+int ss_debug_calib_copy(const float* in, float* out, uint64_t n, void* stream) {
+  if (!in || !out) return fail(SS_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(ss::calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     (size_t)n);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 // tuning aid: per-phase shader-clock totals (all zeros unless the library was built with -DSS_PROFILE_PHASES)
 int ss_debug_phase_cycles(ss_env* env, unsigned long long* out16, int reset) {
   if (!env || !out16) return fail(SS_ERR_INVALID, "null argument");

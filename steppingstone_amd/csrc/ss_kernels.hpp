@@ -524,6 +524,14 @@ __global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
 }
 #endif  // SS_HOST_HARNESS
 
+#ifndef SS_HOST_HARNESS
+// PMC calibration: a dword-per-lane coalesced copy with the step kernel's access shape (tools/hbm_traffic.py)
+__global__ void calib_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] + 1.0f;
+}
+#endif
+
 // packed [N,185] <-> structure of arrays (PHYSICS / include/steppingstone.h layout)
 SSD void pack_env(const Params& P, int e, float* packed) {
   const size_t np = (size_t)P.npad;
