@@ -356,6 +356,7 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
       contact* c = &ct[f * 4 + k];
       memset(c, 0, sizeof *c);
       for (int i = 0; i < 3; ++i) c->r[i] = M->corners[k][i];
+      if (f == 1) c->r[1] = -c->r[1];   /* the left sole's corner list is the mirror image of the right one's */
       real P[3];
       m3v(&w->Rw[b], c->r, P);
       for (int i = 0; i < 3; ++i) { P[i] += w->pw[b][i]; fr->sole[f][i] += (real)0.25 * P[i]; }
@@ -434,11 +435,15 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     if (bn[k] > VCORR_MAX) bn[k] = VCORR_MAX;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
   }
-  for (int it = 0; it < PGS_ITERS; ++it)
+  /* Gauss-Seidel inside each foot, Jacobi between the feet: during a sweep every row sees its own foot's twist
+   * up to date, and the other foot's impulses of THIS sweep only once both feet have finished it. */
+  for (int it = 0; it < PGS_ITERS; ++it) {
+    real Vnext[12];
+    memcpy(Vnext, V, sizeof Vnext);
     for (int k = 0; k < 8; ++k) {
       contact* c = &ct[k];
       if (!c->active) continue;
-      int f = k / 4;
+      int f = k / 4, g = 1 - f;
       for (int d = 0; d < 3; ++d) {
         real y[12], A = 0, vrel = 0;
         for (int i = 0; i < 12; ++i) { y[i] = 0; for (int l = 0; l < 6; ++l) y[i] += Li[i][f * 6 + l] * W[k][d][l]; }
@@ -449,9 +454,15 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
         else { real lim = mu * c->lam[0]; lam_new = r_clamp(lam_new, -lim, lim); }
         real dl = lam_new - c->lam[d];
         c->lam[d] = lam_new;
-        for (int i = 0; i < 12; ++i) V[i] += y[i] * dl;
+        for (int i = 0; i < 6; ++i) {
+          V[f * 6 + i] += y[f * 6 + i] * dl;          /* own foot: immediately (also tracked in Vnext) */
+          Vnext[f * 6 + i] += y[f * 6 + i] * dl;
+          Vnext[g * 6 + i] += y[g * 6 + i] * dl;      /* other foot: visible from the next sweep on */
+        }
       }
     }
+    memcpy(V, Vnext, sizeof Vnext);
+  }
   /* apply accumulated foot wrenches to the whole tree */
   memset(fimp, 0, sizeof fimp);
   for (int k = 0; k < 8; ++k) {

@@ -67,10 +67,11 @@ inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
 
 template <bool RANDOM>
 int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
+  const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane workgroup
   if (env->kind == SS_WALKER3D)
-    hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid64(env), dim3(ss::kWave), 0, st, env->P, io);
+    hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
   else
-    hipLaunchKernelGGL((ss::step_kernel<ss::ModelMike, RANDOM>), grid64(env), dim3(ss::kWave), 0, st, env->P, io);
+    hipLaunchKernelGGL((ss::step_kernel<ss::ModelMike, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
   SS_HIP(hipGetLastError());
   return SS_OK;
 }

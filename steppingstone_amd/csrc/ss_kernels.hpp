@@ -37,6 +37,14 @@ struct Params {
 
 using Cache = Stones;    // active stones n-1, n, n+1: centre, normal, tilts (ss_dynamics.hpp)
 
+struct Dyn {             // full-robot dynamic state, true world (reset / obs / temp-state kernels)
+  float pos[3];
+  float quat[4];
+  SV v0;                 // base twist, body coordinates
+  float q[NJ];
+  float qd[NJ];
+};
+
 SSD float yaw_sample(int i) { return (-20.0f + 4.0f * (float)i) * kDeg; }
 SSD float pitch_sample(int j) { return (-30.0f + 6.0f * (float)j) * kDeg; }
 
@@ -72,7 +80,8 @@ SSD int sample_cell(const Params& P, int e, float u) {
 }
 
 // draw stone k from stone k-1 (terrain table), write it to the table; returns dr and the new stone's data
-SSD float draw_stone(const Params& P, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3], float out_t[2]) {
+SSD float draw_stone(const Params& P, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3], float out_t[2],
+                     bool store = true) {
   uint32_t r[4];
   env_block(P, e, ctr, r);
   int cell = sample_cell(P, e, u01(r[0]));
@@ -94,8 +103,10 @@ SSD float draw_stone(const Params& P, int e, uint32_t& ctr, int k, float out_p[3
   out_p[2] = pz + dr * sp;
   out_t[0] = xt; out_t[1] = yt;
   stone_normal(phi, xt, yt, out_n);
-  T[(k * 6 + 0) * np] = out_p[0]; T[(k * 6 + 1) * np] = out_p[1]; T[(k * 6 + 2) * np] = out_p[2];
-  T[(k * 6 + 3) * np] = phi; T[(k * 6 + 4) * np] = xt; T[(k * 6 + 5) * np] = yt;
+  if (store) {
+    T[(k * 6 + 0) * np] = out_p[0]; T[(k * 6 + 1) * np] = out_p[1]; T[(k * 6 + 2) * np] = out_p[2];
+    T[(k * 6 + 3) * np] = phi; T[(k * 6 + 4) * np] = xt; T[(k * 6 + 5) * np] = yt;
+  }
   return dr;
 }
 
@@ -265,38 +276,68 @@ struct StepIO {
   uint64_t t;         // action-stream index for RANDOM_ACT
 };
 
-// one control step of env e_raw (lane-private LDS column `lane` of lds4); PHYSICS.md section 4
+// draw of the reset joint noise for global joint gj (PHYSICS.md section 7); r = the 6 Philox blocks of the reset
+template <class Model, int GJ>
+SSD float reset_angle(const uint32_t (&r)[6][4]) {
+  constexpr float q0 = Model::q0[GJ], lo = Model::lo[GJ] + 0.02f, hi = Model::hi[GJ] - 0.02f;
+  float q = q0 + 0.05f * (2.f * u01(r[GJ / 4][GJ % 4]) - 1.f);
+  return fminf(fmaxf(q, lo), hi);
+}
+
+// One control step, lane `lane_global` = 2*env + side (side 0: right half, true world; side 1: left half, mirrored
+// world).  PHYSICS.md section 4.  Env-level logic runs redundantly (and identically) in both lanes in the true world.
 template <class Model, bool RANDOM_ACT>
-SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float* lds) {
+SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, float* lds) {
+  const int e_raw = lane_global >> 1, side = lane_global & 1;
   const bool valid = e_raw < P.n;
   const int e = valid ? e_raw : P.n - 1;
   const size_t np = (size_t)P.npad;
+  const float m = side ? -1.f : 1.f;            // y-mirror factor of this lane's world
+  const Lds L{lds, lane};
+  const float* F = P.fstate + e;
 
-  Dyn s;
-  Cache c;
-  load_dyn(P, e, s);
+  Cache c;                                      // true world
   load_cache(P, e, c);
-  float pot_prev = P.fstate[e + F_POT * np], z_init = P.fstate[e + F_ZINIT * np];
-  float ep_ret = P.fstate[e + F_EPRET * np], nn_dr = P.fstate[e + F_NNDR * np];
+  float pot_prev = F[F_POT * np], z_init = F[F_ZINIT * np];
+  float ep_ret = F[F_EPRET * np], nn_dr = F[F_NNDR * np];
   int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
   uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
 
-  // 1. clipped actions -> LDS (read by every substep's pass 2 and by the reward)
-  const Lds L{lds, lane};
+  // 1. this lane's half of the state, mirrored for the left lane, straight into LDS
+  L.s(S_POS + 0) = F[(F_POS + 0) * np]; L.s(S_POS + 1) = m * F[(F_POS + 1) * np]; L.s(S_POS + 2) = F[(F_POS + 2) * np];
+  L.s(S_QUAT + 0) = F[(F_QUAT + 0) * np]; L.s(S_QUAT + 1) = m * F[(F_QUAT + 1) * np];
+  L.s(S_QUAT + 2) = F[(F_QUAT + 2) * np]; L.s(S_QUAT + 3) = m * F[(F_QUAT + 3) * np];
+  L.s(S_VW + 0) = m * F[(F_VEL + 0) * np]; L.s(S_VW + 1) = F[(F_VEL + 1) * np]; L.s(S_VW + 2) = m * F[(F_VEL + 2) * np];
+  L.s(S_VV + 0) = F[(F_VEL + 3) * np]; L.s(S_VV + 1) = m * F[(F_VEL + 4) * np]; L.s(S_VV + 2) = F[(F_VEL + 5) * np];
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    L.s(S_STP + sl * 3 + 0) = c.p[sl][0]; L.s(S_STP + sl * 3 + 1) = m * c.p[sl][1]; L.s(S_STP + sl * 3 + 2) = c.p[sl][2];
+    L.s(S_STN + sl * 3 + 0) = c.nrm[sl][0]; L.s(S_STN + sl * 3 + 1) = m * c.nrm[sl][1]; L.s(S_STN + sl * 3 + 2) = c.nrm[sl][2];
+  }
+  uint32_t ra[6][4];
   if constexpr (RANDOM_ACT) {
-    uint32_t r[6][4];
 #pragma unroll
     for (int b = 0; b < 6; ++b)
-      philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r[b]);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) L.s(S_ACT + j) = 2.f * u01(r[j / 4][j % 4]) - 1.f;
-  } else {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) L.s(S_ACT + j) = fminf(fmaxf(io.act[(size_t)e * NJ + j], -1.f), 1.f);
+      philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
   }
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);         // the left twin of a right-side joint
+    const int gj = side ? jl : jr;
+    const float sg = mirror_flips(jr) ? m : 1.f;
+    L.s(S_Q + k) = sg * F[(F_Q + gj) * np];
+    L.s(S_QD + k) = sg * F[(F_QD + gj) * np];
+    float a;
+    if constexpr (RANDOM_ACT) {
+      const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
+      a = 2.f * u01(bits) - 1.f;
+    } else {
+      a = fminf(fmaxf(io.act[(size_t)e * NJ + gj], -1.f), 1.f);
+    }
+    L.s(S_ACT + k) = sg * a;
+  });
 
   // 2. four substeps on the LDS-resident state
-  dyn_to_lds(s, c, L);
   FootReport fr;
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
   Prof prof;
@@ -307,28 +348,54 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) substep<Model>(SS_PROF_ARG P.power, fr, L);
   SS_PROF(12);
-  dyn_from_lds(s, L);
 
-  // 3-4
+  // 3-4. back to the true world; the pair shares its feet
+  float pos[3] = {L.s(S_POS), m * L.s(S_POS + 1), L.s(S_POS + 2)};
+  float quat[4] = {L.s(S_QUAT), m * L.s(S_QUAT + 1), L.s(S_QUAT + 2), m * L.s(S_QUAT + 3)};
+  SV v0 = {{m * L.s(S_VW), L.s(S_VW + 1), m * L.s(S_VW + 2)}, {L.s(S_VV), m * L.s(S_VV + 1), L.s(S_VV + 2)}};
   elapsed += 1;
-  int flags = fr.contact;
-  bool finite = true;
-  {
-    float accv = s.pos[0] + s.pos[1] + s.pos[2] + s.quat[0] + s.quat[1] + s.quat[2] + s.quat[3];
+  const float my_sole[3] = {fr.sole[0], m * fr.sole[1], fr.sole[2]};
+  float ot_sole[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) accv += s.v0.w[i] + s.v0.v[i];
+  for (int i = 0; i < 3; ++i) ot_sole[i] = xchg(my_sole[i]);
+  const int ot_contact = xchg_i(fr.contact), ot_target = xchg_i(fr.on_target);
+  float sole[2][3];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) accv += s.q[j] + s.qd[j];
-    finite = finite_bits(accv);
-  }
+  for (int i = 0; i < 3; ++i) { sole[0][i] = side ? ot_sole[i] : my_sole[i]; sole[1][i] = side ? my_sole[i] : ot_sole[i]; }
+  int flags = side ? (ot_contact | (fr.contact << 1)) : (fr.contact | (ot_contact << 1));
+  const int on_target = fr.on_target | ot_target;
+  // partial sums over this lane's joints (the spine is counted by the right lane only)
+  float accv = 0.f, e_sum = 0.f, a2 = 0.f;
+  int at_limit = 0;
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    constexpr float mid = 0.5f * (Model::lo[jr] + Model::hi[jr]);
+    constexpr float span = Model::hi[jr] - Model::lo[jr];
+    const float q = L.s(S_Q + k), qd = L.s(S_QD + k), a = L.s(S_ACT + k);
+    const bool mine = (jr >= 3) || (side == 0);
+    accv += q + qd;
+    if (mine) {
+      e_sum += fabsf(a * (0.1f * qd));
+      a2 += a * a;
+      if (fabsf(2.f * (q - mid) / span) > 0.99f) at_limit += 1;
+    }
+  });
+  accv += pos[0] + pos[1] + pos[2] + quat[0] + quat[1] + quat[2] + quat[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accv += v0.w[i] + v0.v[i];
+  e_sum += xchg(e_sum);
+  a2 += xchg(a2);
+  at_limit += xchg_i(at_limit);
+  const bool finite = finite_bits(accv) && (xchg_i(finite_bits(accv) ? 1 : 0) != 0);
+
   // 5. target logic
   float target_old[3] = {c.p[1][0], c.p[1][1], c.p[1][2]};
   float step_bonus = 0.f;
   int advanced = 0;
-  if (fr.on_target != 0) {
+  if (on_target != 0) {
     count += 1;
     if (count == 1) {
-      float d0 = planar_dist(fr.sole[0], target_old), d1 = planar_dist(fr.sole[1], target_old);
+      float d0 = planar_dist(sole[0], target_old), d1 = planar_dist(sole[1], target_old);
       step_bonus = 50.f * expf(-fminf(d0, d1) / 0.25f);
     }
     if (count >= 2 && n < kNumStones - 1) {
@@ -342,39 +409,28 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
       }
       c.tilt[0][0] = c.tilt[1][0]; c.tilt[0][1] = c.tilt[1][1];
       c.tilt[1][0] = c.tilt[2][0]; c.tilt[1][1] = c.tilt[2][1];
-      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2]);
+      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], valid && side == 0);
     }
   }
   // 6. progress
-  float pot = -planar_dist(target_old, s.pos) / kDt;
+  float pot = -planar_dist(target_old, pos) / kDt;
   float progress = pot - pot_prev;
-  pot_prev = advanced ? -planar_dist(c.p[1], s.pos) / kDt : pot;
+  pot_prev = advanced ? -planar_dist(c.p[1], pos) / kDt : pot;
   // 7-8
-  float target_bonus = (n == kNumStones - 1 && planar_dist(c.p[1], s.pos) < 0.15f) ? 2.f : 0.f;
-  float zs = fminf(fr.sole[0][2], fr.sole[1][2]);
-  float tall_bonus = (s.pos[2] - zs > 0.7f) ? 2.f : -1.f;
+  float target_bonus = (n == kNumStones - 1 && planar_dist(c.p[1], pos) < 0.15f) ? 2.f : 0.f;
+  float zs = fminf(sole[0][2], sole[1][2]);
+  float tall_bonus = (pos[2] - zs > 0.7f) ? 2.f : -1.f;
   float zlow = fminf(fminf(c.p[0][2], c.p[1][2]), c.p[2][2]);
-  bool d = (tall_bonus < 0.f) || (s.pos[2] < zlow + 0.3f) || !finite;
+  bool d = (tall_bonus < 0.f) || (pos[2] < zlow + 0.3f) || !finite;
   bool timeout = elapsed >= SS_MAX_EPISODE_STEPS;
   int bad = (timeout && !d) ? 1 : 0;
   d = d || timeout;
   // 9. reward
   float roll, pitch, yaw;
-  quat_rpy(s.quat, roll, pitch, yaw);
+  quat_rpy(quat, roll, pitch, yaw);
   float posture = 0.f;
   if (!(pitch > -0.2f && pitch < 0.4f)) posture += fabsf(pitch);
   if (!(roll > -0.4f && roll < 0.4f)) posture += fabsf(roll);
-  float e_sum = 0.f, a2 = 0.f;
-  int at_limit = 0;
-  static_for<0, NJ>([&](auto Jc) {
-    constexpr int j = decltype(Jc)::value;
-    constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
-    constexpr float span = Model::hi[j] - Model::lo[j];
-    const float aj = L.s(S_ACT + j);
-    e_sum += fabsf(aj * (0.1f * s.qd[j]));
-    a2 += aj * aj;
-    if (fabsf(2.f * (s.q[j] - mid) / span) > 0.99f) at_limit += 1;
-  });
   float energy = (4.5f / NJ) * (e_sum / NJ) + (0.225f / NJ) * (a2 / NJ);
   float r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - 0.1f * (float)at_limit;
   if (!finite || !finite_bits(r)) r = 0.f;
@@ -386,30 +442,114 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
   inf.bad_transition = bad;
   inf.steps_reached = n;
   inf.update_terrain = advanced;
-  if (d && P.auto_reset) {
-    env_reset<Model>(P, e, s, c, ctr, pot_prev, z_init, nn_dr);
+  const bool do_reset = d && P.auto_reset;
+  uint32_t rr[6][4];
+  if (do_reset) {
+    // PHYSICS.md section 7: provisional terrain, standing pose, joint noise from 6 Philox blocks
+    if (valid && side == 0) {
+      float* T = P.terrain + e;
+#pragma unroll 1
+      for (int k = 0; k < kNumStones; ++k) {
+        T[(k * 6 + 0) * np] = 0.75f * (float)k;
+#pragma unroll
+        for (int i = 1; i < 6; ++i) T[(k * 6 + i) * np] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
+      c.nrm[sl][0] = 0.f; c.nrm[sl][1] = 0.f; c.nrm[sl][2] = 1.f;
+      c.tilt[sl][0] = 0.f; c.tilt[sl][1] = 0.f;
+    }
+    pos[0] = 0.f; pos[1] = 0.f; pos[2] = Model::stand_height + 0.01f;
+    quat[0] = 1.f; quat[1] = quat[2] = quat[3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { v0.w[i] = 0.f; v0.v[i] = 0.f; }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) env_block(P, e, ctr, rr[b]);
+    z_init = pos[2];
+    nn_dr = 0.75f;
+    pot_prev = -planar_dist(c.p[1], pos) / kDt;
     n = 1; count = 0; elapsed = 0; flags = 0; ep_ret = 0.f;
   }
+  // joint values of this lane in the TRUE world (after the optional reset)
+  float qt[NH], qdt[NH];
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+    const float sg = mirror_flips(jr) ? m : 1.f;
+    if (do_reset) {
+      qt[k] = side ? reset_angle<Model, jl>(rr) : reset_angle<Model, jr>(rr);
+      qdt[k] = 0.f;
+    } else {
+      qt[k] = sg * L.s(S_Q + k);
+      qdt[k] = sg * L.s(S_QD + k);
+    }
+  });
   if (valid) {
-    float o[SS_OBS_DIM];
-    write_obs<Model>(s, z_init, flags, c, o);
+    float* Fo = P.fstate + e;
     float* op = io.obs + (size_t)e * SS_OBS_DIM;
+    // per-joint state + observation entries: own limbs by each lane, spine by the right lane
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+      const int gj = side ? jl : jr;
+      if (jr >= 3 || side == 0) {
+        // normalisation with the TRUE joint's range: a mirrored x/z joint has range (-hi, -lo)
+        constexpr float midr = 0.5f * (Model::lo[jr] + Model::hi[jr]);
+        constexpr float span = Model::hi[jr] - Model::lo[jr];
+        const float mid = (side && mirror_flips(jr)) ? -midr : midr;
+        Fo[(F_Q + gj) * np] = qt[k];
+        Fo[(F_QD + gj) * np] = qdt[k];
+        op[6 + gj] = clip5(2.f * (qt[k] - mid) / span);
+        op[27 + gj] = clip5(0.1f * qdt[k]);
+      }
+    });
+    if (side == 0) {
+      float R[3][3];
+      quat_rot(quat, R);
+      float vw[3];
 #pragma unroll
-    for (int i = 0; i < SS_OBS_DIM; ++i) op[i] = o[i];
-    io.rew[e] = r;
-    io.done[e] = d ? 1 : 0;
-    if (io.info) io.info[e] = inf;
-    store_dyn(P, e, s);
-    if (advanced || d) store_cache(P, e, c);
-    P.fstate[e + F_POT * np] = pot_prev;
-    P.fstate[e + F_ZINIT * np] = z_init;
-    P.fstate[e + F_EPRET * np] = ep_ret;
-    P.fstate[e + F_NNDR * np] = nn_dr;
-    P.istate[e + I_N * np] = n;
-    P.istate[e + I_COUNT * np] = count;
-    P.istate[e + I_ELAPSED * np] = elapsed;
-    P.istate[e + I_RNG * np] = (int)ctr;
-    P.istate[e + I_FLAGS * np] = flags;
+      for (int i = 0; i < 3; ++i) vw[i] = R[i][0] * v0.v[0] + R[i][1] * v0.v[1] + R[i][2] * v0.v[2];
+      float r2, p2, y2;
+      quat_rpy(quat, r2, p2, y2);
+      float sy, cy;
+      sincosf(y2, &sy, &cy);
+      op[0] = clip5(pos[2] - z_init);
+      op[1] = clip5(cy * vw[0] + sy * vw[1]);
+      op[2] = clip5(-sy * vw[0] + cy * vw[1]);
+      op[3] = clip5(vw[2]);
+      op[4] = clip5(r2);
+      op[5] = clip5(p2);
+      op[48] = (flags & 1) ? 1.f : 0.f;
+      op[49] = (flags & 2) ? 1.f : 0.f;
+      float t[5];
+      target_features(pos, y2, c.p[1], c.tilt[1], t);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) op[50 + i] = t[i];
+      target_features(pos, y2, c.p[2], c.tilt[2], t);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) op[55 + i] = t[i];
+      io.rew[e] = r;
+      io.done[e] = d ? 1 : 0;
+      if (io.info) io.info[e] = inf;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Fo[(F_POS + i) * np] = pos[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Fo[(F_QUAT + i) * np] = quat[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { Fo[(F_VEL + i) * np] = v0.w[i]; Fo[(F_VEL + 3 + i) * np] = v0.v[i]; }
+      if (advanced || do_reset) store_cache(P, e, c);
+      Fo[F_POT * np] = pot_prev;
+      Fo[F_ZINIT * np] = z_init;
+      Fo[F_EPRET * np] = ep_ret;
+      Fo[F_NNDR * np] = nn_dr;
+      P.istate[e + I_N * np] = n;
+      P.istate[e + I_COUNT * np] = count;
+      P.istate[e + I_ELAPSED * np] = elapsed;
+      P.istate[e + I_RNG * np] = (int)ctr;
+      P.istate[e + I_FLAGS * np] = flags;
+    }
   }
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
   SS_PROF(13);
@@ -422,7 +562,7 @@ SSD void step_env(const Params& P, const StepIO& io, int e_raw, int lane, float*
 template <class Model, bool RANDOM_ACT>
 __global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
   __shared__ float4 lds4[kLdsSlots * kWave];
-  step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, reinterpret_cast<float*>(lds4));
+  step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, reinterpret_cast<float*>(lds4));   // lane = 2*env + side
 }
 #endif  // SS_HOST_HARNESS
 

@@ -4,11 +4,42 @@
 // library contains no host path.  Build: hipcc --cuda-host-only -x hip ... (see tests/host_lib.py).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../steppingstone_amd/csrc/ss_kernels.hpp"
+
+// ---- lane-pair exchange on the host: the two lanes of an env run as two threads that meet at every exchange
+namespace {
+struct PairSync {
+  std::atomic<int> arrived{0};
+  std::atomic<int> generation{0};
+  float slot[2];
+  void barrier() {
+    int g = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) == 1) {
+      arrived.store(0, std::memory_order_relaxed);
+      generation.store(g + 1, std::memory_order_release);
+    } else {
+      while (generation.load(std::memory_order_acquire) == g) std::this_thread::yield();
+    }
+  }
+};
+thread_local PairSync* t_sync = nullptr;
+thread_local int t_side = 0;
+}  // namespace
+
+float ss_host_xchg(float x) {
+  PairSync* s = t_sync;
+  s->slot[t_side] = x;
+  s->barrier();
+  float r = s->slot[1 - t_side];
+  s->barrier();
+  return r;
+}
 
 namespace {
 void window_prob(float* p, int c) {
@@ -44,8 +75,17 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   ss::StepIO io{act, obs, rew, done, info, 0};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
   for (int e = 0; e < n; ++e) {
-    if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, e, e % 64, reinterpret_cast<float*>(lds.data()));
-    else ss::step_env<ss::ModelMike, false>(P, io, e, e % 64, reinterpret_cast<float*>(lds.data()));
+    PairSync sync;
+    auto run = [&](int side) {
+      t_sync = &sync;
+      t_side = side;
+      const int lg = 2 * e + side;
+      if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, lg, lg % 64, reinterpret_cast<float*>(lds.data()));
+      else ss::step_env<ss::ModelMike, false>(P, io, lg, lg % 64, reinterpret_cast<float*>(lds.data()));
+    };
+    std::thread other(run, 1);
+    run(0);
+    other.join();
   }
   for (int e = 0; e < n; ++e) ss::pack_env(P, e, packed_out);
   return 0;

@@ -21,7 +21,7 @@ def build():
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     subprocess.check_call(["hipcc", "--cuda-host-only", "-x", "hip", "-O1", "-std=c++17", "-fPIC", "-shared",
-                           "-fno-signed-zeros", "-fno-math-errno", "-DSS_HOST_HARNESS", SRC, "-o", LIB], stderr=subprocess.DEVNULL)
+                           "-fno-signed-zeros", "-fno-math-errno", "-DSS_HOST_HARNESS", "-pthread", SRC, "-o", LIB], stderr=subprocess.DEVNULL)
     return LIB
 
 

@@ -19,7 +19,7 @@ env.rollout_random(50, 0)
 lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
 env.rollout_random(steps, 50)
 lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
-waves = (n + 63) // 64
+waves = (n + 31) // 32      # two lanes per env: 32 envs per wavefront
 per = out.astype(np.float64) / (waves * steps)
 tot = per.sum()
 print("cycles per wave per control step: %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400.0))
