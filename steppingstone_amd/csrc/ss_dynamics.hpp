@@ -26,7 +26,10 @@ constexpr float kH = 1.0f / 240.0f;
 constexpr float kDt = 1.0f / 60.0f;
 constexpr float kGrav = 9.8f;
 constexpr float kStoneR2 = 0.25f * 0.25f;
-constexpr int kPgsIters = 8;
+#ifndef SS_PGS_ITERS
+#define SS_PGS_ITERS 8
+#endif
+constexpr int kPgsIters = SS_PGS_ITERS;
 constexpr float kErp = 0.2f;
 constexpr float kSlop = 0.001f;
 constexpr float kVcorrMax = 2.0f;
@@ -64,7 +67,9 @@ constexpr int first_child_half(int b) {
 struct Prof { uint32_t t[16]; uint32_t last; };
 #define SS_PROF_DECL Prof& prof,
 #define SS_PROF_ARG prof,
-#define SS_PROF(i) do { uint32_t _n = (uint32_t)__builtin_amdgcn_s_memtime(); prof.t[i] += _n - prof.last; prof.last = _n; } while (0)
+// wave-uniform accounting (readfirstlane keeps the counters in SGPRs, so divergent branches do not skew them)
+#define SS_PROF(i) do { uint32_t _n = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_amdgcn_s_memtime()); \
+    prof.t[i] = __builtin_amdgcn_readfirstlane(prof.t[i] + (_n - __builtin_amdgcn_readfirstlane(prof.last))); prof.last = _n; } while (0)
 #else
 struct Prof { int unused; };
 #define SS_PROF_DECL
@@ -98,6 +103,10 @@ struct JointCache {
   Chol6 L0;
 };
 constexpr int half_pos(int j) { return j <= 7 ? j : j - 5; }   // 13..16 -> 8..11
+// Source-level interleaving of the two independent chains (leg, arm) so that neighbouring instructions belong to
+// different dependency chains: one wavefront per SIMD issues a dependent v_fma every ~7 cycles but independent
+// ones every ~2.5 (tools/probes/issue_probe.hip).  Root -> leaves order and its reverse.
+constexpr int kOrderDown[NH] = {0, 1, 2, 3, 13, 4, 14, 5, 15, 6, 16, 7};
 
 // ---- lane-pair exchange.  Partner data lives in the mirrored world: reflect on receipt.
 SSD float xchg(float x) {
@@ -213,20 +222,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   });
   SS_PROF(1);
 
-  // ---- pass 1: velocities (kept in LDS; the chain predecessor stays in registers)
+  // ---- pass 1: velocities (kept in LDS; each chain's predecessor stays in registers)
   {
     const SV v0 = base_twist(L);
-    SV prev = v0;
-    static_for<0, NH>([&](auto Kc) {
-      constexpr int k = decltype(Kc)::value, j = kHalf[k], b = j + 1, p = kParent[j], ax = kAxis[j];
-      SV vp;
-      if constexpr (p == 0) vp = v0;
-      else vp = prev;                                   // chains: spine -> leg consecutive, the arm starts at the torso
-      static_assert(p == 0 || (k > 0 && p == kHalf[k > 0 ? k - 1 : 0] + 1), "tree shape");
-      SV v = xmotion<Model, j>(jc.r[k].cs, jc.r[k].sn, vp);
+    SV prev_leg = v0, prev_arm = v0;                    // spine+leg chain, arm chain
+    static_for<0, NH>([&](auto Ic) {
+      constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, ax = kAxis[j];
+      constexpr bool arm = j >= 13;
+      SV v = xmotion<Model, j>(jc.r[k].cs, jc.r[k].sn, arm ? prev_arm : prev_leg);
       v.w[ax] += L.s(S_QD + k);
       vel_put<b>(L, v);
-      prev = v;
+      if constexpr (arm) prev_arm = v; else prev_leg = v;
     });
   }
   SS_MEMBAR();
@@ -235,8 +241,8 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   // ---- pass 2: articulated inertias, leaves -> root over the half-tree
   ABI acc[NB];
   SV pacc[NB];
-  static_rfor<NH - 1, 0>([&](auto Kc) {
-    constexpr int k = decltype(Kc)::value, j = kHalf[k], b = j + 1, p = kParent[j], ax = kAxis[j];
+  static_rfor<NH - 1, 0>([&](auto Ic) {
+    constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, p = kParent[j], ax = kAxis[j];
     constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
     constexpr bool leaf = first_child_half(b) < 0;
     constexpr bool massive = Model::mass[b] != 0.f;
@@ -312,7 +318,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) { pp.w[i] += po.w[i]; pp.v[i] += po.v[i]; }
     }
-    if constexpr (b == first_child_half(p)) {
+    if constexpr (b == first_child_half(p)) {   // the arm (body 14) reaches the torso before the spine (body 1)
       acc[p] = Ip;
       pacc[p] = pp;
     } else {
@@ -340,18 +346,16 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   }
   SS_PROF(4);
 
-  // ---- pass 3: accelerations -> free velocities (to LDS)
+  // ---- pass 3: accelerations -> free velocities (to LDS), leg and arm chains interleaved
   {
-    SV prev = a0;
-    static_for<0, NH>([&](auto Kc) {
-      constexpr int k = decltype(Kc)::value, j = kHalf[k], b = j + 1, p = kParent[j], ax = kAxis[j];
+    SV prev_leg = a0, prev_arm = a0;
+    static_for<0, NH>([&](auto Ic) {
+      constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, ax = kAxis[j];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+      constexpr bool arm = j >= 13;
       const JRec& r = jc.r[k];
       const SV vb = vel_get<b>(L);
-      SV ap;
-      if constexpr (p == 0) ap = a0;
-      else ap = prev;
-      SV a = xmotion<Model, j>(r.cs, r.sn, ap);
+      SV a = xmotion<Model, j>(r.cs, r.sn, arm ? prev_arm : prev_leg);
       float qd = L.s(S_QD + k);
       a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
       a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
@@ -359,7 +363,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
                    r.Uv[2] * a.v[2];
       float qdd = r.Dinv * (r.u - dotv);
       a.w[ax] += qdd;
-      prev = a;
+      if constexpr (arm) prev_arm = a; else prev_leg = a;
       L.s(S_QDF + k) = qd + h * qdd;
     });
   }
@@ -461,33 +465,61 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   for (int k = 0; k < NH; ++k) dqd[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dv0.w[i] = 0.f; dv0.v[i] = 0.f; }
+#ifdef SS_ABLATE_CONTACT
+  if (false) {
+#else
   if (pair_active != 0) {
+#endif
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     float ul[NH];
-    // unit impulses on the own foot: own-foot twist (Lambda_own column) and pelvis twist (G column)
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) {
+    // unit impulses on the own foot: own-foot twist (Lambda_own column) and pelvis twist (G column).  Three
+    // independent recursions per loop iteration (ILP, see kOrderDown): columns i, i+2, i+4.
+#ifndef SS_LAM_ILP
+#define SS_LAM_ILP 1   // measured: 1 -> 0.1293, 2 -> 0.1336, 3 -> 0.1332 ms/step (standing regime, 4096 envs)
+#endif
+    auto unit_column = [&](int i, float* ulc) {
       SV p;
 #pragma unroll
       for (int m = 0; m < 3; ++m) { p.w[m] = (i == m) ? -1.f : 0.f; p.v[m] = (i == m + 3) ? -1.f : 0.f; }
-      static_rfor<7, 0>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
+      static_rfor<7, 0>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ulc, p); });
       SV d = chol6_solve_neg(jc.L0, p);
-      static_for<0, 3>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ul, d, nullptr); });
+      static_for<0, 3>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ulc, d, nullptr); });
       L.q4(kLdsG + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
       L.q4(kLdsG + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
-      static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ul, d, nullptr); });
+      static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ulc, d, nullptr); });
       L.q4(kLdsLam + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
       L.q4(kLdsLam + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
-    }
-    // unit pelvis twists through the unloaded own leg: T column
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) {
+    };
+    auto t_column = [&](int i) {
       SV d;
 #pragma unroll
       for (int m = 0; m < 3; ++m) { d.w[m] = (i == m) ? 1.f : 0.f; d.v[m] = (i == m + 3) ? 1.f : 0.f; }
       static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, false>(jc, ul, d, nullptr); });
       L.q4(kLdsT + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
       L.q4(kLdsT + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
+    };
+#pragma unroll 1
+    for (int i = 0; i < 6 / SS_LAM_ILP; ++i) {
+      float ul1[NH], ul2[NH];
+      unit_column(i, ul);
+#if SS_LAM_ILP >= 2
+      unit_column(i + 6 / SS_LAM_ILP, ul1);
+#endif
+#if SS_LAM_ILP >= 3
+      unit_column(i + 2 * (6 / SS_LAM_ILP), ul2);
+#endif
+      (void)ul1; (void)ul2;
+    }
+    // unit pelvis twists through the unloaded own leg: T columns
+#pragma unroll 1
+    for (int i = 0; i < 6 / SS_LAM_ILP; ++i) {
+      t_column(i);
+#if SS_LAM_ILP >= 2
+      t_column(i + 6 / SS_LAM_ILP);
+#endif
+#if SS_LAM_ILP >= 3
+      t_column(i + 2 * (6 / SS_LAM_ILP));
+#endif
     }
     SS_PROF(7);
     // own-foot twist under the free velocities
@@ -613,6 +645,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     }
     SS_PROF(9);
     // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down
+#ifndef SS_ABLATE_FINAL
     {
       SV p = {{-W.w[0], -W.w[1], -W.w[2]}, {-W.v[0], -W.v[1], -W.v[2]}};
       static_rfor<7, 3>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
@@ -632,6 +665,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         d = imp_down<Model, j, false>(jc, ul, d, &dqd[half_pos(j)]);
       });
     }
+#endif
   }
   SS_MEMBAR();
   SS_PROF(10);
