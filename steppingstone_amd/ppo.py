@@ -1,0 +1,248 @@
+"""Device-resident PPO driver for the vectorised stepping-stone env.
+
+Counterpart of the reference's training loop, re-organised so that nothing leaves the GPU between env.step() and the
+learner:
+  * actor / critic-ensemble networks     common/controller.py:55-145,217-261   (same architecture and init)
+  * rollout storage + GAE                algorithms/storage.py:5-82            (tensors on the env's device)
+  * clipped-surrogate update             algorithms/ppo.py:40-108              (same loss, Adam, grad clip)
+  * rollout / curriculum / LR schedule   playground/train.py:211-222,363-469,503-506
+The per-env Python loops of train.py:446-456 (bad_masks, episode rewards, masks) are tensor ops here.  The loss and
+one optimiser step are pinned against the reference's own PPO.update (tests/test_ppo_golden.py).
+"""
+import math
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import harness
+from ._lib import ACT_DIM, OBS_DIM
+
+
+class Actor(nn.Module):
+    """SoftsignActor (common/controller.py:217-261): 60 -> 256 x5 -> 21, softsign x3, relu x2, tanh."""
+
+    def __init__(self, state_dim=OBS_DIM, action_dim=ACT_DIM, h_size=256):
+        super().__init__()
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.fc1 = nn.Linear(state_dim, h_size)
+        self.fc2 = nn.Linear(h_size, h_size)
+        self.fc3 = nn.Linear(h_size, h_size)
+        self.fc4 = nn.Linear(h_size, h_size)
+        self.fc5 = nn.Linear(h_size, h_size)
+        self.out = nn.Linear(h_size, action_dim)
+
+    def forward(self, x):
+        x = F.softsign(self.fc1(x))
+        x = F.softsign(self.fc2(x))
+        x = F.softsign(self.fc3(x))
+        x = F.relu(self.fc4(x))
+        x = F.relu(self.fc5(x))
+        return torch.tanh(self.out(x))
+
+
+def _critic(state_dim, h_size=256):
+    gain = nn.init.calculate_gain("relu")
+    layers, d = [], state_dim
+    for width in (h_size, h_size, h_size, h_size, 1):
+        lin = nn.Linear(d, width)
+        nn.init.orthogonal_(lin.weight.data, gain=gain)
+        nn.init.constant_(lin.bias.data, 0)
+        layers += [lin, nn.ReLU()]
+        d = width
+    return nn.Sequential(*layers[:-1])
+
+
+class ActorCritic(nn.Module):
+    """Policy (common/controller.py:55-145): tanh-mean diagonal Gaussian with a state-independent log-std (init -1.5)
+    and an ensemble of value networks whose mean is the value estimate."""
+
+    def __init__(self, state_dim=OBS_DIM, action_dim=ACT_DIM, num_ensembles=1, noise=-1.5):
+        super().__init__()
+        self.actor = Actor(state_dim, action_dim)
+        self.logstd = nn.Parameter(torch.full((action_dim,), float(noise)))
+        self.critics = nn.ModuleList([_critic(state_dim) for _ in range(num_ensembles)])
+
+    def reset_dist(self):
+        self.logstd.data.fill_(-2.5)
+
+    def get_ensemble_values(self, obs):
+        return torch.cat([c(obs) for c in self.critics], dim=-1)
+
+    def get_value(self, obs):
+        return self.get_ensemble_values(obs).mean(dim=-1, keepdim=True)
+
+    def _logp(self, mean, action):
+        var = (2 * self.logstd).exp()
+        return (-((action - mean) ** 2) / (2 * var) - self.logstd - 0.5 * math.log(2 * math.pi)).sum(-1, keepdim=True)
+
+    def act(self, obs, deterministic=False):
+        mean = self.actor(obs)
+        action = mean if deterministic else mean + self.logstd.exp() * torch.randn_like(mean)
+        return self.get_value(obs), action, self._logp(mean, action)
+
+    def evaluate_actions(self, obs, action):
+        mean = self.actor(obs)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + self.logstd).sum()      # per-sample entropy is constant
+        return self.get_ensemble_values(obs), self._logp(mean, action), entropy
+
+
+def ppo_loss(ac, obs, act, value_preds, returns, old_logp, adv, clip_param=0.2, use_clipped_value_loss=False):
+    """The three loss terms of algorithms/ppo.py:64-85 for one minibatch."""
+    values, logp, entropy = ac.evaluate_actions(obs, act)
+    ratio = torch.exp(logp - old_logp)
+    surr1 = ratio * adv
+    surr2 = torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param) * adv
+    action_loss = -torch.min(surr1, surr2).mean()
+    if use_clipped_value_loss:
+        clipped = value_preds + (values - value_preds).clamp(-clip_param, clip_param)
+        value_loss = 0.5 * torch.max((values - returns).pow(2), (clipped - returns).pow(2)).mean()
+    else:
+        value_loss = 0.5 * (returns - values).pow(2).mean()
+    return value_loss, action_loss, entropy
+
+
+class PPO:
+    """algorithms/ppo.py:6-108 on device tensors (defaults of playground/train.py:72-82)."""
+
+    def __init__(self, ac, clip_param=0.2, ppo_epoch=10, mini_batch_size=1024, value_loss_coef=1.0, entropy_coef=0.0,
+                 lr=3e-4, eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None):
+        self.ac = ac
+        self.clip_param, self.ppo_epoch, self.mini_batch_size = clip_param, ppo_epoch, mini_batch_size
+        self.value_loss_coef, self.entropy_coef, self.max_grad_norm = value_loss_coef, entropy_coef, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.mirror_indices = mirror_indices
+        self.optimizer = torch.optim.Adam(ac.parameters(), lr=lr, eps=eps)
+
+    def _allreduce_grads(self):
+        """Data-parallel learner: one RCCL all-reduce of the flattened gradient per minibatch (no-op on one rank)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        grads = [p.grad for p in self.ac.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat /= dist.get_world_size()
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+
+    def set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+
+    def step_minibatch(self, obs, act, value_preds, returns, old_logp, adv):
+        if self.mirror_indices is not None:
+            obs, act = harness.mirror_batch(obs, act, self.mirror_indices)
+            value_preds, returns, old_logp, adv = (t.repeat((2, 1)) for t in (value_preds, returns, old_logp, adv))
+        vl, al, ent = ppo_loss(self.ac, obs, act, value_preds, returns, old_logp, adv, self.clip_param,
+                               self.use_clipped_value_loss)
+        self.optimizer.zero_grad()
+        (vl * self.value_loss_coef + al - ent * self.entropy_coef).backward()
+        self._allreduce_grads()
+        nn.utils.clip_grad_norm_(self.ac.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        return vl.detach(), al.detach(), ent.detach()
+
+    def update(self, roll):
+        adv = roll.returns[:-1] - roll.value_preds[:-1]
+        adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+        T, N = roll.rewards.shape[:2]
+        flat = lambda t: t.reshape(T * N, -1)   # noqa: E731
+        obs, act = flat(roll.obs[:-1]), flat(roll.actions)
+        vp, ret, lp, adv = flat(roll.value_preds[:-1]), flat(roll.returns[:-1]), flat(roll.logp), flat(adv)
+        stats = torch.zeros(3, device=obs.device)
+        count = 0
+        for _ in range(self.ppo_epoch):
+            perm = torch.randperm(T * N, device=obs.device)
+            for s in range(0, T * N, self.mini_batch_size):
+                idx = perm[s:s + self.mini_batch_size]
+                out = self.step_minibatch(obs[idx], act[idx], vp[idx], ret[idx], lp[idx], adv[idx])
+                stats += torch.stack(out)
+                count += 1
+        return (stats / max(count, 1)).tolist()
+
+
+class Rollouts:
+    """RolloutStorage (algorithms/storage.py:5-57) on the env's device."""
+
+    def __init__(self, num_steps, num_envs, device):
+        T, N = num_steps, num_envs
+        z = lambda *s: torch.zeros(*s, device=device)   # noqa: E731
+        self.obs, self.actions = z(T + 1, N, OBS_DIM), z(T, N, ACT_DIM)
+        self.rewards, self.logp = z(T, N, 1), z(T, N, 1)
+        self.value_preds, self.returns = z(T + 1, N, 1), z(T + 1, N, 1)
+        self.masks, self.bad_masks = torch.ones(T + 1, N, 1, device=device), torch.ones(T + 1, N, 1, device=device)
+        self.step = 0
+
+    def insert(self, obs, action, logp, value, reward, mask, bad_mask):
+        t = self.step
+        self.obs[t + 1].copy_(obs); self.actions[t].copy_(action); self.logp[t].copy_(logp)
+        self.value_preds[t].copy_(value); self.rewards[t].copy_(reward)
+        self.masks[t + 1].copy_(mask); self.bad_masks[t + 1].copy_(bad_mask)
+        self.step = (t + 1) % self.rewards.shape[0]
+
+    def after_update(self):
+        self.obs[0].copy_(self.obs[-1]); self.masks[0].copy_(self.masks[-1]); self.bad_masks[0].copy_(self.bad_masks[-1])
+
+    def compute_returns(self, next_value, use_gae=True, gamma=0.99, gae_lambda=0.95):
+        self.returns = harness.compute_returns(self.rewards, self.value_preds, self.masks, self.bad_masks, next_value,
+                                               use_gae, gamma, gae_lambda)
+        if use_gae:
+            self.value_preds[-1] = next_value
+
+
+def collect(envs, ac, roll, num_steps, ep_returns):
+    """The rollout loop of playground/train.py:363-469 with tensorised bookkeeping.  `envs` returns device tensors
+    (SteppingStoneVecEnv(return_numpy=False) or ShardedVecEnv).  Finished episodes' returns are appended to
+    ep_returns (a list of tensors)."""
+    for _ in range(num_steps):
+        with torch.no_grad():
+            value, action, logp = ac.act(roll.obs[roll.step])
+        obs, rew, done, info = envs.step(action)
+        d = done.to(torch.float32).unsqueeze(1)
+        mask = 1.0 - d
+        bad_mask = 1.0 - info["bad_transition"].to(torch.float32).unsqueeze(1)
+        if bool(done.any()):
+            ep_returns.append(info["ep_ret"][done].clone())
+        roll.insert(obs, action, logp, value, rew.unsqueeze(1), mask, bad_mask)
+
+
+def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curriculum=True, use_mirror=False, lr=3e-4,
+          gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print):
+    """Fixed-order-curriculum PPO (playground/train.py:115-118,211-222,503-521).  Returns the list of per-update stats."""
+    torch.manual_seed(seed)
+    dev = envs.device if hasattr(envs, "device") else envs.local.device
+    ac = ActorCritic(num_ensembles=num_ensembles).to(dev)
+    mirror = envs.get_mirror_indices() if use_mirror and hasattr(envs, "get_mirror_indices") else None
+    agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror)
+    n = envs.num_envs
+    roll = Rollouts(num_steps, n, dev)
+    curriculum = 0
+    if use_curriculum:
+        envs.update_curriculum(curriculum)
+    roll.obs[0].copy_(envs.reset())
+    recent, history, start = [], [], time.time()
+    for j in range(num_updates):
+        agent.set_lr(harness.exponential_decay(j, 0.99, lr, 3e-5))
+        ep = []
+        collect(envs, ac, roll, num_steps, ep)
+        recent = (recent + ep)[-50:]
+        mean_ret = float(torch.cat(recent).mean()) if recent else float("nan")
+        if use_curriculum and recent and mean_ret > 1000 and curriculum <= 4:
+            curriculum += 1
+            envs.update_curriculum(curriculum)
+        with torch.no_grad():
+            next_value = ac.get_value(roll.obs[-1])
+        roll.compute_returns(next_value, True, gamma, gae_lambda)
+        vl, al, ent = agent.update(roll)
+        roll.after_update()
+        frames = (j + 1) * num_steps * n
+        stats = {"iter": j + 1, "total_num_steps": frames, "fps": int(frames / (time.time() - start)), "entropy": ent,
+                 "value_loss": vl, "action_loss": al, "mean_rew": mean_ret, "curriculum": curriculum}
+        history.append(stats)
+        if log:
+            log(stats)
+    return ac, history

@@ -258,3 +258,14 @@ def test_single_env_facade_and_errors():
     env.close()
     with pytest.raises(SteppingStoneError):
         make_env("NoSuchEnv-v0")
+
+
+def test_ppo_driver_end_to_end_on_gpu():
+    """BASELINE configs[4] in miniature: Mike, curriculum on, device-resident PPO for two updates."""
+    from steppingstone_amd import ppo
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    envs = SteppingStoneVecEnv("MikeStepperEnv-v0", 512, seed=8, device="cuda:0", return_numpy=False)
+    ac, hist = ppo.train(envs, num_updates=2, num_steps=16, ppo_epoch=2, mini_batch_size=1024, use_mirror=True, log=None)
+    assert len(hist) == 2 and all(np.isfinite([h["value_loss"], h["action_loss"], h["entropy"]]).all() for h in hist)
+    assert next(ac.parameters()).is_cuda
+    envs.close()

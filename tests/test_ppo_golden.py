@@ -1,0 +1,77 @@
+"""The device-resident PPO pieces (steppingstone_amd/ppo.py) against the reference's own Policy + PPO.update run on
+a fixed batch from fixed weights (tools/make_golden.py section 5), plus an end-to-end smoke of the driver on the oracle-
+backed env.  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+from steppingstone_amd import ppo
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "harness_golden.npz"))
+
+
+def load_reference_weights(ac, prefix):
+    sd = {}
+    for k in G.files:
+        if not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        t = torch.from_numpy(G[k])
+        if name == "dist.logstd._bias":
+            sd["logstd"] = t.reshape(-1)
+        elif name.startswith("c"):
+            i, rest = name[1:].split(".", 1)
+            sd["critics.%s.%s" % (i, rest)] = t
+        else:
+            sd[name] = t
+    ac.load_state_dict(sd, strict=True)
+
+
+def test_one_ppo_update_matches_reference():
+    ac = ppo.ActorCritic(num_ensembles=2)
+    load_reference_weights(ac, "ppo_w0/")
+    T, N = G["ppo_act"].shape[:2]
+    t = lambda k: torch.from_numpy(G["ppo_" + k])  # noqa: E731
+    roll = ppo.Rollouts(T, N, torch.device("cpu"))
+    roll.obs.copy_(t("obs")); roll.actions.copy_(t("act")); roll.logp.copy_(t("old_logp"))
+    roll.value_preds.copy_(t("vpred")); roll.returns.copy_(t("returns"))
+    agent = ppo.PPO(ac, clip_param=0.2, ppo_epoch=1, mini_batch_size=T * N, lr=3e-4, eps=1e-5, max_grad_norm=2.0)
+    vl, al, ent = agent.update(roll)
+    assert np.allclose([vl, al, ent], G["ppo_losses"], rtol=2e-5, atol=2e-6), ([vl, al, ent], G["ppo_losses"])
+    ref = ppo.ActorCritic(num_ensembles=2)
+    load_reference_weights(ref, "ppo_w1/")
+    for (name, p), (_, q) in zip(ac.state_dict().items(), ref.state_dict().items()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=2e-6), name
+    # the step moved the weights at all
+    moved = ppo.ActorCritic(num_ensembles=2)
+    load_reference_weights(moved, "ppo_w0/")
+    assert (moved.actor.fc1.weight - ac.actor.fc1.weight).abs().max() > 1e-5
+
+
+def test_actor_critic_shapes_and_logp():
+    torch.manual_seed(0)
+    ac = ppo.ActorCritic(num_ensembles=3)
+    obs = torch.randn(7, 60)
+    v, a, lp = ac.act(obs)
+    assert v.shape == (7, 1) and a.shape == (7, 21) and lp.shape == (7, 1)
+    vals, lp2, ent = ac.evaluate_actions(obs, a)
+    assert vals.shape == (7, 3) and torch.allclose(lp, lp2, atol=1e-5)
+    d = torch.distributions.Normal(ac.actor(obs), ac.logstd.exp())
+    assert torch.allclose(d.log_prob(a).sum(-1, keepdim=True), lp2, atol=1e-5)
+    assert torch.allclose(d.entropy().sum(-1).mean(), ent, atol=1e-5)
+    _, a_det, _ = ac.act(obs, deterministic=True)
+    assert torch.equal(a_det, ac.actor(obs))
+
+
+def test_driver_runs_on_oracle_backed_env():
+    from oracle_backend import OracleBackend
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    n = 16
+    envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n, seed=1, return_numpy=False, backend=OracleBackend(1, n, 1))
+    logs = []
+    ac, hist = ppo.train(envs, num_updates=2, num_steps=8, num_ensembles=2, ppo_epoch=2, mini_batch_size=64,
+                         use_mirror=True, log=logs.append)
+    assert len(hist) == 2 and hist[-1]["total_num_steps"] == 2 * 8 * n
+    assert all(np.isfinite([h["value_loss"], h["action_loss"], h["entropy"]]).all() for h in hist)
+    assert hist[-1]["curriculum"] == 0

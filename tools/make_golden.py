@@ -156,6 +156,34 @@ def main():
         assert obs_seq[0].dtype == np.float32 and rew_seq[0].dtype == np.float64 and done_seq[0].dtype == bool
         envs.close()
 
+    # ---- 5. one PPO update (algorithms/ppo.py:40-108) from a fixed initialisation on a fixed batch
+    from algorithms.ppo import PPO
+    from common.controller import Policy, SoftsignActor
+    torch.manual_seed(1234)
+    ac = Policy(SoftsignActor(ToyEnv()), num_ensembles=2)
+    sd0 = {k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+    T, N = 4, 8
+    st = RolloutStorage(T, N, (60,), 21, 1)
+    obs = torch.from_numpy(rng.normal(size=(T + 1, N, 60)).astype(np.float32))
+    act = torch.from_numpy(rng.normal(size=(T, N, 21)).astype(np.float32) * 0.5)
+    with torch.no_grad():
+        _, logp0, _, _ = ac.evaluate_actions(obs[:-1].view(-1, 60), None, None, act.view(-1, 21))
+    old_logp = logp0.view(T, N, 1) + torch.from_numpy(rng.normal(size=(T, N, 1)).astype(np.float32)) * 0.3
+    vpred = torch.from_numpy(rng.normal(size=(T + 1, N, 1)).astype(np.float32))
+    rets = torch.from_numpy(rng.normal(size=(T + 1, N, 1)).astype(np.float32))
+    st.observations.copy_(obs); st.actions.copy_(act); st.action_log_probs.copy_(old_logp)
+    st.value_preds.copy_(vpred); st.returns.copy_(rets)
+    agent = PPO(ac, clip_param=0.2, ppo_epoch=1, num_mini_batch=1, value_loss_coef=1.0, entropy_coef=0.0, lr=3e-4, eps=1e-5,
+                max_grad_norm=2.0, use_clipped_value_loss=False)
+    vl, al, ent = agent.update(st)
+    sd1 = {k: v.detach().clone().numpy() for k, v in ac.state_dict().items()}
+    out.update({"ppo_obs": obs.numpy(), "ppo_act": act.numpy(), "ppo_old_logp": old_logp.numpy(), "ppo_vpred": vpred.numpy(),
+                "ppo_returns": rets.numpy(), "ppo_losses": np.array([vl, al, ent])})
+    for k, v in sd0.items():
+        out["ppo_w0/" + k] = v
+    for k, v in sd1.items():
+        out["ppo_w1/" + k] = v
+
     path = os.path.join(ROOT, "tests", "golden", "harness_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
