@@ -210,6 +210,36 @@ def collect(envs, ac, roll, num_steps, ep_returns):
         roll.insert(obs, action, logp, value, rew.unsqueeze(1), mask, bad_mask)
 
 
+def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_threshold=0.85, events=5, max_steps=400):
+    """Adaptive / threshold curriculum sampler (playground/train.py:229-272, 320-361), batched: the evaluation envs
+    are rolled with the deterministic policy; every env that advances to a new target contributes the critic-ensemble
+    value of its 121 hypothetical next stones (create_temp_states); after `events` such contributions the summed
+    11x11 metric, normalised by its absolute maximum, becomes softmax(-10 |m - threshold|) ("threshold") or
+    softmax(-10 m) ("adaptive").  Returns an (11,11) float64 numpy grid for update_sample_prob."""
+    dev = eval_envs.device
+    obs = eval_envs.reset()
+    total = torch.zeros(121, device=dev)
+    seen = 0
+    for _ in range(max_steps):
+        with torch.no_grad():
+            _, action, _ = ac.act(obs, deterministic=True)
+        obs, _, _, info = eval_envs.step(action)
+        hit = info["update_terrain"] > 0
+        if bool(hit.any()):
+            temp = eval_envs.create_temp_states()[hit]                      # [k,121,60]
+            with torch.no_grad():
+                v = ac.get_ensemble_values(temp.reshape(-1, temp.shape[-1])).mean(dim=-1)
+            total += v.view(-1, 121).sum(dim=0)
+            seen += int(hit.sum())
+            if seen >= events:
+                break
+    if seen == 0:
+        return None
+    m = total / total.abs().max()
+    logits = -10.0 * (m - curriculum_threshold).abs() if mode == "threshold" else -10.0 * m
+    return torch.softmax(logits, dim=0).view(11, 11).double().cpu().numpy()
+
+
 def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curriculum=True, use_mirror=False, lr=3e-4,
           gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print):
     """Fixed-order-curriculum PPO (playground/train.py:115-118,211-222,503-521).  Returns the list of per-update stats."""

@@ -75,3 +75,31 @@ def test_driver_runs_on_oracle_backed_env():
     assert len(hist) == 2 and hist[-1]["total_num_steps"] == 2 * 8 * n
     assert all(np.isfinite([h["value_loss"], h["action_loss"], h["entropy"]]).all() for h in hist)
     assert hist[-1]["curriculum"] == 0
+
+
+def test_adaptive_sampler_grid():
+    from oracle_backend import OracleBackend
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    import oracle_lib as ol
+    n = 12
+    be = OracleBackend(0, n, 3)
+    envs = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=3, return_numpy=False, backend=be)
+    envs.update_curriculum(5)
+    torch.manual_seed(0)
+    ac = ppo.ActorCritic(num_ensembles=2)
+    # make the target advance quickly: start every env standing on its target stone
+    orig_reset = envs.reset
+
+    def reset_on_target():
+        orig_reset()
+        st = be.o.get_state()
+        st[:, 0] = st[:, 65 + 6]
+        be.o.set_state(st)
+        return envs.get_obs()
+
+    envs.reset = reset_on_target
+    for mode in ("threshold", "adaptive"):
+        p = ppo.sampling_probs_from_values(ac, envs, mode=mode, events=3, max_steps=6)
+        assert p is not None and p.shape == (11, 11) and p.dtype == np.float64
+        assert abs(p.sum() - 1.0) < 1e-6 and (p > 0).all()      # softmax is evaluated in fp32 like the reference
+        envs.update_sample_prob(np.repeat(p[None], n, axis=0))      # what train.py:267-271 does
