@@ -44,6 +44,7 @@ typedef SSO_REAL real;
 #define GRAV ((real)9.8)
 #define STONE_R ((real)0.25)
 #define PGS_ITERS 8
+#define PGS_WARM 0
 #define ERP ((real)0.2)
 #define SLOP ((real)0.001)
 #define VCORR_MAX ((real)2.0)
@@ -378,14 +379,22 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
   }
 }
 
+/* solver knobs: PHYSICS.md 3.4 fixes them; sso_debug_set_solver() exists only for the convergence study of
+ * tools/pgs_convergence.py */
+static int g_pgs_iters = PGS_ITERS;
+static int g_pgs_warm = PGS_WARM;
+void sso_debug_set_solver(int iters, int warm) { g_pgs_iters = iters; g_pgs_warm = warm; }
+
+typedef struct { real lam[8][3]; int stone[8]; } warm_state;   /* impulses of the previous substep of this step */
+
 /* PHYSICS.md 3.3-3.4: returns dqd/dv0 to add to the free velocities */
 static void contact_solve(const sso_model* M, const work* w, const real* qd_free, const real* v0_free,
-                          contact ct[8], real* dqd, real* dv0) {
+                          contact ct[8], warm_state* ws, real* dqd, real* dv0) {
   memset(dqd, 0, sizeof(real) * NJ);
   memset(dv0, 0, sizeof(real) * 6);
   int any = 0;
   for (int k = 0; k < 8; ++k) any |= ct[k].active;
-  if (!any) return;
+  if (!any) { for (int k = 0; k < 8; ++k) ws->stone[k] = -1; return; }
   const int foot_body[2] = {RFOOT, LFOOT};
   /* Lambda^-1 by 12 unit impulses */
   real Li[12][12];
@@ -435,9 +444,21 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     if (bn[k] > VCORR_MAX) bn[k] = VCORR_MAX;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
   }
+  /* warm start: a corner that touched the same stone in the previous substep of this control step starts from
+   * that substep's impulses (applied to the twists before the first sweep) */
+  if (g_pgs_warm)
+    for (int k = 0; k < 8; ++k) {
+      contact* c = &ct[k];
+      if (!c->active || ws->stone[k] != c->stone) continue;
+      int f = k / 4;
+      for (int d = 0; d < 3; ++d) {
+        c->lam[d] = ws->lam[k][d];
+        for (int i = 0; i < 12; ++i) { real y = 0; for (int l = 0; l < 6; ++l) y += Li[i][f * 6 + l] * W[k][d][l]; V[i] += y * c->lam[d]; }
+      }
+    }
   /* Gauss-Seidel inside each foot, Jacobi between the feet: during a sweep every row sees its own foot's twist
    * up to date, and the other foot's impulses of THIS sweep only once both feet have finished it. */
-  for (int it = 0; it < PGS_ITERS; ++it) {
+  for (int it = 0; it < g_pgs_iters; ++it) {
     real Vnext[12];
     memcpy(Vnext, V, sizeof Vnext);
     for (int k = 0; k < 8; ++k) {
@@ -463,6 +484,10 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     }
     memcpy(V, Vnext, sizeof Vnext);
   }
+  for (int k = 0; k < 8; ++k) {
+    ws->stone[k] = ct[k].active ? ct[k].stone : -1;
+    for (int d = 0; d < 3; ++d) ws->lam[k][d] = ct[k].active ? ct[k].lam[d] : 0;
+  }
   /* apply accumulated foot wrenches to the whole tree */
   memset(fimp, 0, sizeof fimp);
   for (int k = 0; k < 8; ++k) {
@@ -474,7 +499,7 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
   memcpy(dv0, dvb[0], sizeof(real) * 6);
 }
 
-static void substep(const sso_model* M, env_state* s, const real* tau_m, foot_report* fr) {
+static void substep(const sso_model* M, env_state* s, const real* tau_m, foot_report* fr, warm_state* ws) {
   work w;
   const real h = H_SUB;
   real qdd[NJ], a0[6], qdf[NJ], v0f[6], dqd[NJ], dv0[6];
@@ -484,7 +509,7 @@ static void substep(const sso_model* M, env_state* s, const real* tau_m, foot_re
   for (int j = 0; j < NJ; ++j) qdf[j] = s->qd[j] + h * qdd[j];
   for (int i = 0; i < 6; ++i) v0f[i] = s->vel[i] + h * a0[i];
   detect(M, s, &w, ct, fr);
-  contact_solve(M, &w, qdf, v0f, ct, dqd, dv0);
+  contact_solve(M, &w, qdf, v0f, ct, ws, dqd, dv0);
   for (int j = 0; j < NJ; ++j) { s->qd[j] = qdf[j] + dqd[j]; s->q[j] += h * s->qd[j]; }
   for (int i = 0; i < 6; ++i) s->vel[i] = v0f[i] + dv0[i];
   real vw[3];
@@ -631,7 +656,9 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
     tau[j] = E->power * M->torque[j] * a[j];
   }
   foot_report fr;
-  for (int k = 0; k < 4; ++k) substep(M, s, tau, &fr);
+  warm_state ws;
+  for (int k = 0; k < 8; ++k) ws.stone[k] = -1;
+  for (int k = 0; k < 4; ++k) substep(M, s, tau, &fr, &ws);
   s->elapsed += 1;
   s->flags = (fr.foot_contact[0] ? 1 : 0) | (fr.foot_contact[1] ? 2 : 0);
   int finite = state_finite(s);
@@ -815,8 +842,10 @@ void sso_debug_aba(int kind, const real* packed, const real* tau_m, real* qdd, r
 /* n substeps with fixed motor torques; state in/out; last foot report out (2 contact flags, 2 target flags) */
 void sso_debug_substeps(sso_env* E, int e, const real* tau_m, int n, int* flags4) {
   foot_report fr;
+  warm_state ws;
   memset(&fr, 0, sizeof fr);
-  for (int k = 0; k < n; ++k) substep(E->M, &E->e[e], tau_m, &fr);
+  for (int k = 0; k < 8; ++k) ws.stone[k] = -1;
+  for (int k = 0; k < n; ++k) substep(E->M, &E->e[e], tau_m, &fr, &ws);
   flags4[0] = fr.foot_contact[0]; flags4[1] = fr.foot_contact[1];
   flags4[2] = fr.foot_on_target[0]; flags4[3] = fr.foot_on_target[1];
 }

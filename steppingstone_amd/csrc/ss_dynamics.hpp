@@ -209,6 +209,83 @@ SSD SV imp_down(const JointCache& jc, const float* ul, const SV& dpar, float* dq
   return d;
 }
 
+// ---- inverse articulated inertia ("Omega") recursion, used for the contact-space operators
+//   Omega_b maps an impulse on body b to the twist change of body b (all joints free):
+//   Omega_0 = (I^A_0)^-1,  Omega_child = P Omega_parent P^T + S D^-1 S^T,  P = (1 - S D^-1 U^T) X_J
+struct OMG {       // [[W, X], [X^T, V]] : w = W n + X f,  v = X^T n + V f
+  Sym3 W;
+  float X[3][3];
+  Sym3 V;
+};
+SSD void sym_full(const Sym3& S, float F[3][3]) {
+  F[0][0] = S.m[0]; F[1][1] = S.m[1]; F[2][2] = S.m[2];
+  F[0][1] = F[1][0] = S.m[3]; F[0][2] = F[2][0] = S.m[4]; F[1][2] = F[2][1] = S.m[5];
+}
+template <class Model, int J>
+SSD OMG omega_step(const JRec& r, const OMG& O) {
+  constexpr int AX = kAxis[J];
+  float Xs[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Xs[i][j] = O.X[i][j];
+  Sym3 V = O.V;
+  // 1. motion-type shift of the origin by r (parent frame):  X' = X + W K,  V' = V + X^T K - K X'   (K = r x)
+  if constexpr (has_offset<Model, J>()) {
+    float Wf[3][3];
+    sym_full(O.W, Wf);
+    float rcx[3][3], rcxs[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float col[3] = {O.X[0][i], O.X[1][i], O.X[2][i]};
+      cross_r<Model, J>(col, rcx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float t[3];
+      cross_r<Model, J>(Wf[i], t);
+      Xs[i][0] -= t[0]; Xs[i][1] -= t[1]; Xs[i][2] -= t[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float col[3] = {Xs[0][j], Xs[1][j], Xs[2][j]};
+      cross_r<Model, J>(col, rcxs[j]);
+    }
+    V.m[0] -= rcx[0][0] + rcxs[0][0];
+    V.m[1] -= rcx[1][1] + rcxs[1][1];
+    V.m[2] -= rcx[2][2] + rcxs[2][2];
+    V.m[3] -= rcx[0][1] + rcxs[1][0];
+    V.m[4] -= rcx[0][2] + rcxs[2][0];
+    V.m[5] -= rcx[1][2] + rcxs[2][1];
+  }
+  // 2. into the child orientation: E M E^T with E = R^T, i.e. a rotation by -q
+  OMG o;
+  o.W = rot_sym<AX>(r.cs, -r.sn, O.W);
+  o.V = rot_sym<AX>(r.cs, -r.sn, V);
+  rot_gen<AX>(r.cs, -r.sn, Xs, o.X);
+  // 3. free joint:  (1 - s u^T) Omega (1 - s u^T)^T + s e^T,  s = D^-1 e_AX (angular slot), u = U
+  float Wf[3][3], Vf[3][3];
+  sym_full(o.W, Wf);
+  sym_full(o.V, Vf);
+  float tw[3], tv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    tw[i] = Wf[i][0] * r.Uw[0] + Wf[i][1] * r.Uw[1] + Wf[i][2] * r.Uw[2] + o.X[i][0] * r.Uv[0] + o.X[i][1] * r.Uv[1] +
+            o.X[i][2] * r.Uv[2];
+    tv[i] = o.X[0][i] * r.Uw[0] + o.X[1][i] * r.Uw[1] + o.X[2][i] * r.Uw[2] + Vf[i][0] * r.Uv[0] + Vf[i][1] * r.Uv[1] +
+            Vf[i][2] * r.Uv[2];
+  }
+  const float alpha = r.Uw[0] * tw[0] + r.Uw[1] * tw[1] + r.Uw[2] * tw[2] + r.Uv[0] * tv[0] + r.Uv[1] * tv[1] + r.Uv[2] * tv[2];
+  const float d = r.Dinv;
+  constexpr int ai = (AX + 1) % 3, aj = (AX + 2) % 3;
+  o.W.template at<AX, ai>() -= d * tw[ai];
+  o.W.template at<AX, aj>() -= d * tw[aj];
+  o.W.template at<AX, AX>() += d * (1.0f + d * alpha - 2.0f * tw[AX]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) o.X[AX][j] -= d * tv[j];
+  return o;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // State (q, qd, base pose/twist), stones and clipped actions of THIS lane's world live in LDS (region B).
 template <class Model>
@@ -498,6 +575,69 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       L.q4(kLdsT + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
       L.q4(kLdsT + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
     };
+#ifdef SS_OMEGA_OPERATORS
+    // Omega recursion (opt-in): ~2.4 k instructions instead of ~4.0 k for six unit-impulse recursions, but measured
+    // no faster (standing regime 0.1307 vs 0.1293 ms/step: its eight steps form one long dependent chain):
+    //   T = K = P_7 ... P_3 (columns by the unloaded down pass), G = Omega_pelvis K^T, Lambda_own = Omega_foot
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) t_column(i);
+    {
+      OMG O;
+      {   // Omega_0 = (L L^T)^-1, column by column
+        float inv[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          SV e;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? -1.f : 0.f; e.v[m] = (i == m + 3) ? -1.f : 0.f; }
+          SV x = chol6_solve_neg(jc.L0, e);
+          inv[0][i] = x.w[0]; inv[1][i] = x.w[1]; inv[2][i] = x.w[2]; inv[3][i] = x.v[0]; inv[4][i] = x.v[1]; inv[5][i] = x.v[2];
+        }
+        O.W.m[0] = inv[0][0]; O.W.m[1] = inv[1][1]; O.W.m[2] = inv[2][2]; O.W.m[3] = inv[0][1]; O.W.m[4] = inv[0][2]; O.W.m[5] = inv[1][2];
+        O.V.m[0] = inv[3][3]; O.V.m[1] = inv[4][4]; O.V.m[2] = inv[5][5]; O.V.m[3] = inv[3][4]; O.V.m[4] = inv[3][5]; O.V.m[5] = inv[4][5];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) O.X[a][b] = inv[a][3 + b];
+      }
+      static_for<0, 3>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
+      {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K)
+        float Wf[3][3], Vf[3][3], Kc[6][6];          // Kc[m][i] = K[i][m] = (T column m)[i]
+        sym_full(O.W, Wf);
+        sym_full(O.V, Vf);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          float4 c0 = L.q4(kLdsT + m * 2 + 0), c1 = L.q4(kLdsT + m * 2 + 1);
+          Kc[m][0] = c0.x; Kc[m][1] = c0.y; Kc[m][2] = c0.z; Kc[m][3] = c0.w; Kc[m][4] = c1.x; Kc[m][5] = c1.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const float n[3] = {Kc[0][i], Kc[1][i], Kc[2][i]}, f[3] = {Kc[3][i], Kc[4][i], Kc[5][i]};
+          float w[3], v[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            w[a] = Wf[a][0] * n[0] + Wf[a][1] * n[1] + Wf[a][2] * n[2] + O.X[a][0] * f[0] + O.X[a][1] * f[1] + O.X[a][2] * f[2];
+            v[a] = O.X[0][a] * n[0] + O.X[1][a] * n[1] + O.X[2][a] * n[2] + Vf[a][0] * f[0] + Vf[a][1] * f[1] + Vf[a][2] * f[2];
+          }
+          L.q4(kLdsG + i * 2 + 0) = make_float4(w[0], w[1], w[2], v[0]);
+          L.q4(kLdsG + i * 2 + 1) = make_float4(v[1], v[2], 0.f, 0.f);
+        }
+      }
+      static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
+      {   // Lambda_own = Omega_foot, stored column-wise
+        float Wf[3][3], Vf[3][3];
+        sym_full(O.W, Wf);
+        sym_full(O.V, Vf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          L.q4(kLdsLam + i * 2 + 0) = make_float4(Wf[0][i], Wf[1][i], Wf[2][i], O.X[i][0]);
+          L.q4(kLdsLam + i * 2 + 1) = make_float4(O.X[i][1], O.X[i][2], 0.f, 0.f);
+          L.q4(kLdsLam + (3 + i) * 2 + 0) = make_float4(O.X[0][i], O.X[1][i], O.X[2][i], Vf[0][i]);
+          L.q4(kLdsLam + (3 + i) * 2 + 1) = make_float4(Vf[1][i], Vf[2][i], 0.f, 0.f);
+        }
+      }
+    }
+#else
 #pragma unroll 1
     for (int i = 0; i < 6 / SS_LAM_ILP; ++i) {
       float ul1[NH], ul2[NH];
@@ -521,6 +661,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       t_column(i + 2 * (6 / SS_LAM_ILP));
 #endif
     }
+#endif
     SS_PROF(7);
     // own-foot twist under the free velocities
     float V[6];

@@ -346,7 +346,10 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   prof.last = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
-  for (int k = 0; k < 4; ++k) substep<Model>(SS_PROF_ARG P.power, fr, L);
+#ifndef SS_NUM_SUBSTEPS
+#define SS_NUM_SUBSTEPS 4
+#endif
+  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model>(SS_PROF_ARG P.power, fr, L);
   SS_PROF(12);
 
   // 3-4. back to the true world; the pair shares its feet
