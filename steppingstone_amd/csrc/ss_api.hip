@@ -68,6 +68,7 @@ inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
 template <bool RANDOM>
 int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
   const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane workgroup
+  SS_HIP(hipSetDevice(env->device));                   // the stream belongs to this device
   if (env->kind == SS_WALKER3D)
     hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
   else
@@ -139,6 +140,7 @@ void ss_destroy(ss_env* env) {
 
 int ss_reset(ss_env* env, float* obs, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
+  SS_HIP(hipSetDevice(env->device));
   hipStream_t st = (hipStream_t)stream;
   if (env->kind == SS_WALKER3D)
     hipLaunchKernelGGL((ss::reset_kernel<ss::ModelWalker3D>), grid64(env), dim3(ss::kWave), 0, st, env->P, obs);
@@ -169,6 +171,7 @@ int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, f
 
 int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream) {
   if (!env || !act) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
   hipLaunchKernelGGL(ss::random_actions_kernel, dim3((env->P.n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      env->P, t, act);
   SS_HIP(hipGetLastError());
@@ -220,6 +223,7 @@ int ss_set_auto_reset(ss_env* env, int32_t on) {
 
 int ss_create_temp_states(ss_env* env, float* out, void* stream) {
   if (!env || !out) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
   const int total = env->P.n * SS_NCELL;
   dim3 grid((total + 255) / 256), block(256);
   if (env->kind == SS_WALKER3D)
@@ -283,6 +287,7 @@ int ss_debug_phase_cycles(ss_env* env, unsigned long long* out16, int reset) {
 
 int ss_get_state(ss_env* env, float* packed, void* stream) {
   if (!env || !packed) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
   hipLaunchKernelGGL(ss::pack_state_kernel, dim3((env->P.n + 63) / 64), dim3(64), 0, (hipStream_t)stream, env->P, packed);
   SS_HIP(hipGetLastError());
   return SS_OK;
@@ -290,6 +295,7 @@ int ss_get_state(ss_env* env, float* packed, void* stream) {
 
 int ss_set_state(ss_env* env, const float* packed, void* stream) {
   if (!env || !packed) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
   hipLaunchKernelGGL(ss::unpack_state_kernel, dim3((env->P.n + 63) / 64), dim3(64), 0, (hipStream_t)stream, env->P, packed);
   SS_HIP(hipGetLastError());
   return SS_OK;
@@ -297,6 +303,7 @@ int ss_set_state(ss_env* env, const float* packed, void* stream) {
 
 int ss_get_obs(ss_env* env, float* obs, void* stream) {
   if (!env || !obs) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
   if (env->kind == SS_WALKER3D)
     hipLaunchKernelGGL((ss::obs_kernel<ss::ModelWalker3D>), grid64(env), dim3(ss::kWave), 0, (hipStream_t)stream, env->P, obs);
   else
