@@ -25,6 +25,8 @@
 #else
 #define SS_FENCE() ((void)0)
 #endif
+// hides a value from CSE so that address arithmetic is redone after a long region instead of being kept live
+#define SS_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SS_RSQRT(x) rsqrtf(x)
 #define SS_UMULHI(a, b) __umulhi((a), (b))
 #define SS_F2U(x) __float_as_uint(x)
@@ -36,6 +38,7 @@ static inline float ss_host_rsqrt(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned ss_host_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline unsigned ss_host_f2u(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }
 #define SS_FENCE() ((void)0)
+#define SS_OPAQUE(x) asm volatile("" : "+r"(x))
 #define SS_RSQRT(x) ss_host_rsqrt(x)
 #define SS_UMULHI(a, b) ss_host_umulhi((a), (b))
 #define SS_F2U(x) ss_host_f2u(x)
