@@ -269,3 +269,50 @@ def test_ppo_driver_end_to_end_on_gpu():
     assert len(hist) == 2 and all(np.isfinite([h["value_loss"], h["action_loss"], h["entropy"]]).all() for h in hist)
     assert next(ac.parameters()).is_cuda
     envs.close()
+
+
+def test_gpu_is_deterministic_and_handles_tiny_batches():
+    outs = []
+    for rep in range(2):
+        g = gpu_env("MikeStepperEnv-v0", 33, seed=17)
+        g.update_curriculum(4)
+        g.reset()
+        acc = []
+        for t in range(40):
+            o, r, d, _ = g.step(g.random_actions(t))
+            acc.append(np.concatenate([o, r[:, None], d[:, None].astype(np.float64)], axis=1))
+        outs.append(np.array(acc))
+        g.close()
+    assert np.array_equal(outs[0], outs[1])           # bitwise run-to-run
+    one = gpu_env("Walker3DStepperEnv-v0", 1, seed=2)
+    o = ol.OracleEnv("walker3d", 1, seed=2)
+    assert np.abs(one.reset() - o.reset()).max() < 1e-6
+    a = o.random_actions(0)
+    og, rg, dg, _ = one.step(a)
+    oo, ro, do, _ = o.step(a)
+    assert np.abs(og - oo).max() < 2e-3 and abs(rg[0] - ro[0]) < 2e-2
+    one.close()
+
+
+def test_episode_statistics_match_oracle():
+    """Distribution-level parity over free-running rollouts (chaotic trajectories diverge, statistics must not):
+    episode lengths and returns of 1024 envs x 150 random-action steps."""
+    n, steps = 1024, 150
+    g = gpu_env("Walker3DStepperEnv-v0", n, seed=31)
+    o = ol.OracleEnv("walker3d", n, seed=31)
+    g.reset()
+    o.reset()
+    lg, lo_, rg_, ro_ = [], [], [], []
+    for t in range(steps):
+        a = o.random_actions(t)
+        _, _, dg, _ = g.step(a)
+        raw = g._info.cpu().numpy()
+        fl = raw[:, 0:2].view(np.float32)
+        lg += list(fl[dg, 1]); rg_ += list(fl[dg, 0])
+        _, _, do, io = o.step(a)
+        m = do.astype(bool)
+        lo_ += list(io["ep_len"][m]); ro_ += list(io["ep_ret"][m])
+    assert len(lg) > 2000 and abs(len(lg) - len(lo_)) < 0.03 * len(lo_)
+    assert abs(np.mean(lg) - np.mean(lo_)) < 0.03 * np.mean(lo_), (np.mean(lg), np.mean(lo_))
+    assert abs(np.mean(rg_) - np.mean(ro_)) < 0.05 * abs(np.mean(ro_)) + 0.5, (np.mean(rg_), np.mean(ro_))
+    g.close()
