@@ -538,6 +538,8 @@ static void env_block(const sso_env* E, int e, env_state* s, uint32_t out[4]) {
   s->rng_ctr += 1;
 }
 
+/* inverse-CDF draw from the 11x11 yaw x pitch grid the trainer pushes with envs.update_sample_prob
+ * (playground/train.py:263-271, 356-360; common/envs_utils.py:568-571, 654-655); PHYSICS.md section 6 */
 static int sample_cell(const float* prob, float u) {
   float cdf = 0.f;
   int last = 0;
@@ -560,7 +562,8 @@ static void place_stone(env_state* s, int k, real yaw, real pitch, real dr, real
   s->terrain[k][5] = yt;
 }
 
-/* draw stone k from stone k-1 (PHYSICS.md section 6); returns dr */
+/* draw stone k from stone k-1 (PHYSICS.md section 6); returns dr.  Counterpart of env.sample_next_next_step() /
+ * terrain_info[next_next_step, 0:6] = x,y,z,phi,x_tilt,y_tilt (playground/enjoy.py:52-64) */
 static real draw_stone(const sso_env* E, int e, env_state* s, int k) {
   uint32_t r[4];
   env_block(E, e, s, r);
@@ -584,6 +587,8 @@ static void target_features(const env_state* s, const real* stone, real yaw, flo
   o[0] = (float)(r_sin(ang) * d); o[1] = (float)(r_cos(ang) * d); o[2] = (float)dz;
   o[3] = (float)stone[4]; o[4] = (float)stone[5];
 }
+/* 60-float observation (dims pinned by the shipped checkpoints): 50 robot + 2 x 5 target features;
+ * PHYSICS.md section 5 */
 static void write_obs(const sso_model* M, const env_state* s, float* o) {
   real roll, pitch, yaw;
   quat_rpy(s->quat, &roll, &pitch, &yaw);
@@ -611,6 +616,7 @@ static void write_obs(const sso_model* M, const env_state* s, float* o) {
 }
 
 /* ------------------------------------------------------------------------------------------------ reset/step */
+/* env.reset() as called by the worker (common/envs_utils.py:643-644, 647-648); PHYSICS.md section 7 */
 static void env_reset(const sso_env* E, int e) {
   const sso_model* M = E->M;
   env_state* s = &E->e[e];
@@ -647,6 +653,9 @@ static int state_finite(const env_state* s) {
   return isfinite((double)acc);
 }
 
+/* env.step(action) + the worker's auto-reset (common/envs_utils.py:645-649: terminal reward/done/info, RESET obs),
+ * Monitor's episode statistics (:131-153), TimeLimitMask's bad_transition (:59-65), env.update_terrain
+ * (playground/train.py:245); PHYSICS.md section 4 */
 static void env_step(const sso_env* E, int e, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info) {
   const sso_model* M = E->M;
   env_state* s = &E->e[e];
@@ -723,6 +732,8 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
 }
 
 /* ------------------------------------------------------------------------------------------------ C API */
+/* update_curriculum(c): uniform over the (2c+1)^2 window around the centre cell [5,5] of the 11x11 grid
+ * (playground/train.py:132-133 prob_filter[5,5], :412 / :555 window [5-c:5+c+1]); update_specialist(s): the ring */
 static void fill_window(float* prob, int c, int ring) {
   int cnt = 0;
   for (int i = 0; i < NGRID; ++i)
@@ -766,6 +777,8 @@ void sso_set_sample_prob(sso_env* E, const double* p, int per_env) {
 }
 void sso_set_power(sso_env* E, double power) { E->power = (real)power; }
 void sso_set_auto_reset(sso_env* E, int on) { E->auto_reset = on ? 1 : 0; }
+/* env.create_temp_states() -> (yaw_size*pitch_size, 60) = (121, 60) hypothetical observations
+ * (playground/train.py:247-257; stacked per env at common/envs_utils.py:573-578); PHYSICS.md section 8 */
 void sso_create_temp_states(sso_env* E, float* out) {
   for (int e = 0; e < E->num_envs; ++e) {
     env_state tmp = E->e[e];
