@@ -293,10 +293,19 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
   SS_PROF(0);
-  static_for<0, NH>([&](auto Kc) {
-    constexpr int k = decltype(Kc)::value;
-    ss_sincos(L.s(S_Q + k), jc.r[k].sn, jc.r[k].cs);
-  });
+  // LDS round trips (~100 cycles) are fully exposed with one wavefront per SIMD, and the compiler issues each
+  // ds_read right before its use: batch the loads of a phase up front / prefetch one joint ahead instead.
+  float qd_all[NH];
+  {
+    float q_all[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) { q_all[k] = L.s(S_Q + k); qd_all[k] = L.s(S_QD + k); }
+    SS_MEMBAR();
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      ss_sincos(q_all[k], jc.r[k].sn, jc.r[k].cs);
+    });
+  }
   SS_PROF(1);
 
   // ---- pass 1: velocities (kept in LDS; each chain's predecessor stays in registers)
@@ -307,7 +316,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, ax = kAxis[j];
       constexpr bool arm = j >= 13;
       SV v = xmotion<Model, j>(jc.r[k].cs, jc.r[k].sn, arm ? prev_arm : prev_leg);
-      v.w[ax] += L.s(S_QD + k);
+      v.w[ax] += qd_all[k];
       vel_put<b>(L, v);
       if constexpr (arm) prev_arm = v; else prev_leg = v;
     });
@@ -318,12 +327,28 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   // ---- pass 2: articulated inertias, leaves -> root over the half-tree
   ABI acc[NB];
   SV pacc[NB];
+  struct JIn { SV vb; float q, a; };
+  auto jin_load = [&](auto Ic) {
+    constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1;
+    JIn r;
+    r.vb = vel_get<b>(L);
+    r.q = L.s(S_Q + k);
+    r.a = L.s(S_ACT + k);
+    return r;
+  };
+  JIn jnext = jin_load(std::integral_constant<int, NH - 1>{});
   static_rfor<NH - 1, 0>([&](auto Ic) {
-    constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, p = kParent[j], ax = kAxis[j];
+    constexpr int idx = decltype(Ic)::value;
+    constexpr int j = kOrderDown[idx], k = half_pos(j), b = j + 1, p = kParent[j], ax = kAxis[j];
     constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
     constexpr bool leaf = first_child_half(b) < 0;
     constexpr bool massive = Model::mass[b] != 0.f;
-    const SV vb = vel_get<b>(L);
+    const JIn jin = jnext;
+    if constexpr (idx > 0) {
+      jnext = jin_load(std::integral_constant<int, (idx > 0 ? idx - 1 : 0)>{});
+      SS_MEMBAR();                                    // keep the prefetch above this joint's arithmetic
+    }
+    const SV vb = jin.vb;
     ABI I;
     SV pA;
     if constexpr (leaf) {
@@ -343,11 +368,11 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
     constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j];
     constexpr float tq = Model::torque[j];
-    float q = L.s(S_Q + k), qd = L.s(S_QD + k);
+    float q = jin.q, qd = qd_all[k];
     float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
     bool lim = viol != 0.f;
     float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
-    float tau_m = power * tq * L.s(S_ACT + k);
+    float tau_m = power * tq * jin.a;
     float tau = tau_m - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
     float Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
     // U = I S
@@ -423,17 +448,24 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   }
   SS_PROF(4);
 
-  // ---- pass 3: accelerations -> free velocities (to LDS), leg and arm chains interleaved
+  // ---- pass 3: accelerations -> free velocities (to LDS), leg and arm chains interleaved, twists prefetched
   {
     SV prev_leg = a0, prev_arm = a0;
+    auto vget = [&](auto Ic) { return vel_get<kOrderDown[decltype(Ic)::value] + 1>(L); };
+    SV vnext = vget(std::integral_constant<int, 0>{});
     static_for<0, NH>([&](auto Ic) {
-      constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, ax = kAxis[j];
+      constexpr int idx = decltype(Ic)::value;
+      constexpr int j = kOrderDown[idx], k = half_pos(j), ax = kAxis[j];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       constexpr bool arm = j >= 13;
       const JRec& r = jc.r[k];
-      const SV vb = vel_get<b>(L);
+      const SV vb = vnext;
+      if constexpr (idx + 1 < NH) {
+        vnext = vget(std::integral_constant<int, (idx + 1 < NH ? idx + 1 : 0)>{});
+        SS_MEMBAR();
+      }
       SV a = xmotion<Model, j>(r.cs, r.sn, arm ? prev_arm : prev_leg);
-      float qd = L.s(S_QD + k);
+      float qd = qd_all[k];
       a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
       a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
       float dotv = r.Uw[0] * a.w[0] + r.Uw[1] * a.w[1] + r.Uw[2] * a.w[2] + r.Uv[0] * a.v[0] + r.Uv[1] * a.v[1] +
@@ -812,11 +844,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   SS_PROF(10);
 
   // ---- integrate (semi-implicit Euler), state back to LDS
+  {
+    float qf[NH], qq[NH];
 #pragma unroll
-  for (int k = 0; k < NH; ++k) {
-    float qd = L.s(S_QDF + k) + dqd[k];
-    L.s(S_QD + k) = qd;
-    L.s(S_Q + k) += h * qd;
+    for (int k = 0; k < NH; ++k) { qf[k] = L.s(S_QDF + k); qq[k] = L.s(S_Q + k); }
+    SS_MEMBAR();
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      float qd = qf[k] + dqd[k];
+      L.s(S_QD + k) = qd;
+      L.s(S_Q + k) = qq[k] + h * qd;
+    }
   }
   SV v0n;
 #pragma unroll
