@@ -68,6 +68,11 @@ int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done
  * actions U(-1,1), one kernel launch per step; t0 = index of the first step in the action stream. */
 int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, float* rew, uint8_t* done,
                       ss_info* info, void* stream);
+/* One step whose results land in ONE packed device buffer [N,62] f32 = obs(60) | rew | done(0/1): the block a
+ * multi-GPU shard all-gathers per step (replaces the per-env pipe + shared-memory traffic of
+ * common/envs_utils.py:550-558,608-620).  use_random_actions != 0: actions from the benchmark Philox stream at index t. */
+int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64_t t, float* packed, ss_info* info,
+                   void* stream);
 /* Same action stream written to act [N,21] (parity tests / external policies). */
 int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream);
 

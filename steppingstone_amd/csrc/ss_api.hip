@@ -153,7 +153,7 @@ int ss_reset(ss_env* env, float* obs, void* stream) {
 int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!act || !obs || !rew || !done) return fail(SS_ERR_INVALID, "act/obs/rew/done must be device pointers");
-  ss::StepIO io{act, obs, rew, done, info, 0};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr};
   return launch_step<false>(env, io, (hipStream_t)stream);
 }
 
@@ -162,11 +162,19 @@ int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, f
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!obs || !rew || !done) return fail(SS_ERR_INVALID, "obs/rew/done must be device pointers");
   for (int32_t k = 0; k < num_steps; ++k) {
-    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k};
+    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr};
     int rc = launch_step<true>(env, io, (hipStream_t)stream);
     if (rc != SS_OK) return rc;
   }
   return SS_OK;
+}
+
+int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64_t t, float* packed, ss_info* info,
+                   void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (!packed || (!act && !use_random_actions)) return fail(SS_ERR_INVALID, "packed (and act, unless random) must be set");
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed};
+  return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
 }
 
 int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream) {

@@ -274,6 +274,8 @@ struct StepIO {
   uint8_t* done;      // [N]
   ss_info* info;      // [N] or null
   uint64_t t;         // action-stream index for RANDOM_ACT
+  float* packed;      // optional [N,62] = obs | rew | done(0/1): the block the multi-GPU all-gather ships; when set,
+                      // obs / rew / done above may be null
 };
 
 // draw of the reset joint noise for global joint gj (PHYSICS.md section 7); r = the 6 Philox blocks of the reset
@@ -504,7 +506,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   // per store instruction (measured 3.1x the algorithmic HBM traffic before this).  The host harness runs lanes one
   // after the other, so it keeps the direct writes.
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int kObsStride = SS_OBS_DIM + 1;           // 61: odd stride, conflict-free ds_write_b32
+  constexpr int kObsStride = SS_OBS_DIM + 3;           // 63: odd stride (conflict-free ds_write_b32), room for rew, done
   float* stage = lds + (lane >> 1) * kObsStride;
   uint32_t* istage = reinterpret_cast<uint32_t*>(lds) + kEnvsPerWave * kObsStride + (lane >> 1) * 5;
 #define SS_OBS(i) stage[i]
@@ -555,13 +557,21 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       target_features(pos, y2, c.p[2], c.tilt[2], t);
 #pragma unroll
       for (int i = 0; i < 5; ++i) SS_OBS(55 + i) = t[i];
-      io.rew[e] = r;
-      io.done[e] = d ? 1 : 0;
+      if (io.rew) io.rew[e] = r;
+      if (io.done) io.done[e] = d ? 1 : 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+      stage[SS_OBS_DIM] = r;
+      stage[SS_OBS_DIM + 1] = d ? 1.f : 0.f;
       istage[0] = SS_F2U(inf.ep_ret); istage[1] = SS_F2U(inf.ep_len);
       istage[2] = (uint32_t)inf.bad_transition; istage[3] = (uint32_t)inf.steps_reached; istage[4] = (uint32_t)inf.update_terrain;
 #else
       if (io.info) io.info[e] = inf;
+      if (io.packed) {
+        float* pk = io.packed + (size_t)e * (SS_OBS_DIM + 2);
+        for (int i = 0; i < SS_OBS_DIM; ++i) pk[i] = op_direct[i];
+        pk[SS_OBS_DIM] = r;
+        pk[SS_OBS_DIM + 1] = d ? 1.f : 0.f;
+      }
 #endif
 #pragma unroll
       for (int i = 0; i < 3; ++i) Fo[(F_POS + i) * np] = pos[i];
@@ -586,11 +596,22 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     SS_MEMBAR();
     const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
     const int nvalid = min(kEnvsPerWave, P.n - env0);
-    float* og = io.obs + (size_t)env0 * SS_OBS_DIM;
+    if (io.obs) {
+      float* og = io.obs + (size_t)env0 * SS_OBS_DIM;
 #pragma unroll 1
-    for (int g = lane; g < nvalid * SS_OBS_DIM; g += kWave) {
-      const int el = g / SS_OBS_DIM, idx = g - el * SS_OBS_DIM;
-      og[g] = lds[el * kObsStride + idx];
+      for (int g = lane; g < nvalid * SS_OBS_DIM; g += kWave) {
+        const int el = g / SS_OBS_DIM, idx = g - el * SS_OBS_DIM;
+        og[g] = lds[el * kObsStride + idx];
+      }
+    }
+    if (io.packed) {
+      constexpr int kPack = SS_OBS_DIM + 2;
+      float* pg = io.packed + (size_t)env0 * kPack;
+#pragma unroll 1
+      for (int g = lane; g < nvalid * kPack; g += kWave) {
+        const int el = g / kPack, idx = g - el * kPack;
+        pg[g] = lds[el * kObsStride + idx];
+      }
     }
     if (io.info) {
       uint32_t* ig = reinterpret_cast<uint32_t*>(io.info + env0);

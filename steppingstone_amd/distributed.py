@@ -26,29 +26,39 @@ class ShardedVecEnv:
         self.observation_space = getattr(local_env, "observation_space", None)
         self.action_space = getattr(local_env, "action_space", None)
         dev = local_env.device
-        self._packed = torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev)
-        self._gathered = torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev)
+        # double-buffered: the all-gather of step t overlaps the kernel of step t+1 in the rollout benchmark
+        self._packed = [torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
+        self._gathered = [torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
+        self._work = [None, None]
 
     # -- helpers
     def local_slice(self):
         return slice(self.rank * self.n_local, (self.rank + 1) * self.n_local)
 
-    def _gather(self, obs, rew, done):
-        self._packed[:, :OBS_DIM] = obs
-        self._packed[:, OBS_DIM] = rew
-        self._packed[:, OBS_DIM + 1] = done.to(torch.float32)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self._gathered, self._packed, group=self.group)
-            g = self._gathered
-        else:
-            g = self._packed
+    @staticmethod
+    def _split(g):
         return g[:, :OBS_DIM], g[:, OBS_DIM], g[:, OBS_DIM + 1] > 0.5
+
+    def _wait(self, slot):
+        if self._work[slot] is not None:
+            self._work[slot].wait()
+            self._work[slot] = None
+
+    def _gather_packed(self, slot, async_op=False):
+        """All-gather the local packed block of `slot` (the step kernel wrote it directly: no extra copies)."""
+        if self.world == 1:
+            return self._packed[slot]
+        w = dist.all_gather_into_tensor(self._gathered[slot], self._packed[slot], group=self.group, async_op=async_op)
+        self._work[slot] = w if async_op else None
+        return self._gathered[slot]
 
     # -- VecEnv protocol on GLOBAL arrays
     def reset(self):
         obs = self.local.reset()
-        zero = torch.zeros(self.n_local, dtype=torch.float32, device=obs.device)
-        return self._gather(obs, zero, zero)[0]
+        self._wait(0)
+        self._packed[0].zero_()
+        self._packed[0][:, :OBS_DIM] = obs
+        return self._split(self._gather_packed(0))[0]
 
     def step(self, actions):
         """actions: (N,21) global (every rank passes the same tensor) or (N/G,21) already local."""
@@ -56,20 +66,25 @@ class ShardedVecEnv:
         if a.shape[0] == self.num_envs and self.world > 1:
             a = a[self.local_slice()]
         assert a.shape == (self.n_local, ACT_DIM)
-        obs, rew, done, info = self.local.step(a)
-        gobs, grew, gdone = self._gather(obs, rew, done)
-        return gobs, grew, gdone, info          # info stays rank-local (episode stats reduce separately)
+        self._wait(0)
+        self.local.step_packed(self._packed[0], actions=a)
+        gobs, grew, gdone = self._split(self._gather_packed(0))
+        return gobs, grew, gdone, self.local._info_tensors()   # info stays rank-local (episode stats reduce separately)
 
     def rollout_random(self, num_steps, t0=0, gather=True):
-        """Benchmark path: each of num_steps steps = one local kernel launch (+ one all-gather when gather)."""
-        out = None
+        """Benchmark path: each of num_steps steps = one local kernel launch writing the packed block + (when
+        gather) one asynchronous all-gather of it, overlapped with the next step's kernel."""
+        slot = 0
         for k in range(num_steps):
-            obs, rew, done = self.local.rollout_random(1, t0 + k)
+            slot = k & 1
+            self._wait(slot)                       # the buffer's previous all-gather (two steps ago) must be done
+            self.local.step_packed(self._packed[slot], actions=None, t=t0 + k)
             if gather:
-                out = self._gather(obs, rew, done)
-            else:
-                out = (obs, rew, done)
-        return out
+                self._gather_packed(slot, async_op=True)
+        self._wait(0)
+        self._wait(1)
+        g = self._gathered[slot] if (gather and self.world > 1) else self._packed[slot]
+        return self._split(g)
 
     def update_curriculum(self, c):
         self.local.update_curriculum(c)

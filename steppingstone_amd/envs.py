@@ -107,6 +107,10 @@ class HipBackend:
         _lib.check(self.lib.ss_rollout_random(self.h, int(num_steps), int(t0), _ptr(obs), _ptr(rew), _ptr(done),
                                               _ptr(info), _stream(self.device)))
 
+    def step_packed(self, act, use_random, t, packed, info):
+        _lib.check(self.lib.ss_step_packed(self.h, _ptr(act) if act is not None else None, 1 if use_random else 0, int(t),
+                                           _ptr(packed), _ptr(info), _stream(self.device)))
+
     def random_actions(self, t, act):
         _lib.check(self.lib.ss_random_actions(self.h, int(t), _ptr(act), _stream(self.device)))
 
@@ -217,6 +221,14 @@ class SteppingStoneVecEnv:
         """BASELINE metric path: num_steps launches with on-device U(-1,1) actions (Philox stream 1)."""
         self.backend.rollout_random(num_steps, t0, self._obs, self._rew, self._done, self._info)
         return self._obs, self._rew, self._done
+
+    def step_packed(self, packed, actions=None, t=0):
+        """One step written into the caller's [N,62] buffer (obs | rew | done): the block ShardedVecEnv all-gathers.
+        actions=None draws them from the benchmark Philox stream at index t."""
+        if actions is not None:
+            self._act.copy_(actions.reshape(self.num_envs, ACT_DIM))
+        self.backend.step_packed(self._act if actions is not None else None, actions is None, t, packed, self._info)
+        return packed
 
     def random_actions(self, t):
         self.backend.random_actions(t, self._act)

@@ -36,6 +36,15 @@ class OracleBackend:
             act.copy_(torch.from_numpy(self.o.random_actions(t0 + k)))
             self.step(act, obs, rew, done, info)
 
+    def step_packed(self, act, use_random, t, packed, info):
+        a = torch.from_numpy(self.o.random_actions(t)) if use_random else act
+        obs, rew = torch.zeros((self.n, 60)), torch.zeros(self.n)
+        done = torch.zeros(self.n, dtype=torch.uint8)
+        self.step(a, obs, rew, done, info)
+        packed[:, :60] = obs
+        packed[:, 60] = rew
+        packed[:, 61] = done.float()
+
     def random_actions(self, t, act):
         act.copy_(torch.from_numpy(self.o.random_actions(t)))
 

@@ -316,3 +316,24 @@ def test_episode_statistics_match_oracle():
     assert abs(np.mean(lg) - np.mean(lo_)) < 0.03 * np.mean(lo_), (np.mean(lg), np.mean(lo_))
     assert abs(np.mean(rg_) - np.mean(ro_)) < 0.05 * abs(np.mean(ro_)) + 0.5, (np.mean(rg_), np.mean(ro_))
     g.close()
+
+
+def test_packed_step_equals_plain_step():
+    """The [N,62] packed output (what a multi-GPU shard all-gathers) carries exactly obs | rew | done of ss_step."""
+    from steppingstone_amd.distributed import ShardedVecEnv
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    n = 200
+    a_env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=6, device="cuda:0", return_numpy=False)
+    b_env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=6, device="cuda:0", return_numpy=False)
+    sh = ShardedVecEnv(b_env)                 # world size 1: no collective, same code path otherwise
+    assert torch.equal(a_env.reset(), sh.reset())
+    for t in range(6):
+        act = a_env.random_actions(t)
+        o1, r1, d1, _ = a_env.step(act)
+        o2, r2, d2, _ = sh.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    o1, r1, d1 = a_env.rollout_random(3, t0=50)
+    o2, r2, d2 = sh.rollout_random(3, t0=50)
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1.bool(), d2)
+    a_env.close()
+    b_env.close()
