@@ -109,16 +109,17 @@ constexpr int half_pos(int j) { return j <= 7 ? j : j - 5; }   // 13..16 -> 8..1
 constexpr int kOrderDown[NH] = {0, 1, 2, 3, 13, 4, 14, 5, 15, 6, 16, 7};
 
 // ---- lane-pair exchange.  Partner data lives in the mirrored world: reflect on receipt.
+// On the device this is a DPP quad_perm [1,0,3,2] move (full VALU rate, no LDS round trip like ds_bpermute).
 SSD float xchg(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __shfl_xor(x, 1);
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 #else
   return ss_host_xchg(x);
 #endif
 }
 SSD int xchg_i(int x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __shfl_xor(x, 1);
+  return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
 #else
   return (int)ss_host_xchg((float)x);
 #endif
