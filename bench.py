@@ -90,7 +90,9 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("SS_FORCE_COLLECTIVE") == "1"      # world 1 under torchrun: still go through RCCL
+    use_dist = world > 1 or (force and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -100,11 +102,11 @@ def main():
         local.update_curriculum(args.curriculum)
     env = ShardedVecEnv(local)
     env.reset()
-    gather = world > 1 and not args.no_gather
+    gather = use_dist and not args.no_gather
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -124,7 +126,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -151,7 +153,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

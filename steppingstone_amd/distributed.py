@@ -5,6 +5,8 @@ backend is "nccl") of the packed [N/G, 62] = [obs | rew | done] block so every r
 rew / done the single-learner loop of playground/train.py:363-469 expects.  Actions flow the other way by slicing.
 Global env ids (env_id_offset = rank * N/G) key the RNG streams, so results do not depend on G.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,6 +23,8 @@ class ShardedVecEnv:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # SS_FORCE_COLLECTIVE=1 issues the all-gather even at world size 1 (exercises the RCCL path on a 1-GPU box)
+        self._collective = self.world > 1 or (dist.is_initialized() and os.environ.get("SS_FORCE_COLLECTIVE") == "1")
         self.n_local = int(local_env.num_envs)
         self.num_envs = self.n_local * self.world
         self.observation_space = getattr(local_env, "observation_space", None)
@@ -46,7 +50,7 @@ class ShardedVecEnv:
 
     def _gather_packed(self, slot, async_op=False):
         """All-gather the local packed block of `slot` (the step kernel wrote it directly: no extra copies)."""
-        if self.world == 1:
+        if not self._collective:
             return self._packed[slot]
         w = dist.all_gather_into_tensor(self._gathered[slot], self._packed[slot], group=self.group, async_op=async_op)
         self._work[slot] = w if async_op else None
@@ -83,7 +87,7 @@ class ShardedVecEnv:
                 self._gather_packed(slot, async_op=True)
         self._wait(0)
         self._wait(1)
-        g = self._gathered[slot] if (gather and self.world > 1) else self._packed[slot]
+        g = self._gathered[slot] if (gather and self._collective) else self._packed[slot]
         return self._split(g)
 
     def update_curriculum(self, c):

@@ -337,3 +337,20 @@ def test_packed_step_equals_plain_step():
     assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1.bool(), d2)
     a_env.close()
     b_env.close()
+
+
+def test_bench_rccl_path_on_one_rank():
+    """bench.py under torch.distributed.run with one rank and SS_FORCE_COLLECTIVE=1: process-group init on RCCL,
+    the per-step asynchronous all-gather of the packed block, barriers and the max-over-ranks reduction all run."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SS_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    js = json.loads(line)
+    assert js["config"]["parallelism"].endswith("+allgather")
+    assert js["value"] > 1e6 and js["n_gpus"] == 1
