@@ -608,12 +608,23 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       L.q4(kLdsT + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
       L.q4(kLdsT + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
     };
-#ifdef SS_OMEGA_OPERATORS
-    // Omega recursion (opt-in): ~2.4 k instructions instead of ~4.0 k for six unit-impulse recursions, but measured
-    // no faster (standing regime 0.1307 vs 0.1293 ms/step: its eight steps form one long dependent chain):
+#ifndef SS_UNIT_COLUMNS
+    // Omega recursion (default; -DSS_UNIT_COLUMNS selects the six unit-impulse recursions instead): ~2.4 k
+    // instructions instead of ~4.0 k.  Measured 0.1194 vs 0.1210 ms/step with three T columns per loop trip:
     //   T = K = P_7 ... P_3 (columns by the unloaded down pass), G = Omega_pelvis K^T, Lambda_own = Omega_foot
+#ifndef SS_T_ILP
+#define SS_T_ILP 3   // measured 1 -> 0.1198, 2 -> 0.1197, 3 -> 0.1194 ms/step
+#endif
 #pragma unroll 1
-    for (int i = 0; i < 6; ++i) t_column(i);
+    for (int i = 0; i < 6 / SS_T_ILP; ++i) {
+      t_column(i);
+#if SS_T_ILP >= 2
+      t_column(i + 6 / SS_T_ILP);
+#endif
+#if SS_T_ILP >= 3
+      t_column(i + 2 * (6 / SS_T_ILP));
+#endif
+    }
     {
       OMG O;
       {   // Omega_0 = (L L^T)^-1, column by column
