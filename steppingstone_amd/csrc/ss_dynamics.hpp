@@ -36,12 +36,10 @@ constexpr float kVcorrMax = 2.0f;
 
 constexpr int kWave = 64;
 constexpr int kEnvsPerWave = 32;
-constexpr int kLdsSlots = 160;         // 160 float4 = 2560 B per lane = 163,840 B per wavefront (all of the CU's LDS)
-constexpr int kSlotsA = 72;
-constexpr int kLdsRows = 0;            // 12 rows x 3 float4: y_own[6], dir[3], 1/A, b_n
-constexpr int kLdsLam = 36;            // 6 columns x 2 float4: own-foot twist per unit impulse on the own foot
-constexpr int kLdsG = 48;              // 6 columns x 2 float4: pelvis twist per unit impulse on the own foot
-constexpr int kLdsT = 60;              // 6 columns x 2 float4: own-foot twist per unit pelvis twist
+constexpr int kLdsSlots = 40;          // 40 float4 = 640 B per lane = 40,960 B per wavefront: four wavefronts (one per SIMD) per CU
+constexpr int kSlotsA = 20;            // region A: ABA-phase body twists (78 scalars), then the contact operators G and T
+constexpr int kLdsG = 0;               // 6 columns x 3 float2: pelvis twist per unit impulse on the own foot
+constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist per unit pelvis twist
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 constexpr int NH = 12;                 // joints per half
 enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_QDF = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
@@ -80,7 +78,7 @@ struct Prof { int unused; };
 struct Lds {       // lane-private view of the workgroup's LDS
   float* base;
   int lane;
-  SSD float4& q4(int slot) const { return reinterpret_cast<float4*>(base)[slot * kWave + lane]; }
+  SSD float2& q2(int item) const { return reinterpret_cast<float2*>(base)[item * kWave + lane]; }   // region A, 8-B items
   SSD float& s(int idx) const { return base[kScalarBase + idx * kWave + lane]; }   // region B scalar
   SSD float& av(int idx) const { return base[idx * kWave + lane]; }                // ABA-phase scalar over region A
 };
@@ -582,36 +580,19 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #endif
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     float ul[NH];
-    // unit impulses on the own foot: own-foot twist (Lambda_own column) and pelvis twist (G column).  Three
-    // independent recursions per loop iteration (ILP, see kOrderDown): columns i, i+2, i+4.
-#ifndef SS_LAM_ILP
-#define SS_LAM_ILP 1   // measured: 1 -> 0.1293, 2 -> 0.1336, 3 -> 0.1332 ms/step (standing regime, 4096 envs)
-#endif
-    auto unit_column = [&](int i, float* ulc) {
-      SV p;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) { p.w[m] = (i == m) ? -1.f : 0.f; p.v[m] = (i == m + 3) ? -1.f : 0.f; }
-      static_rfor<7, 0>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ulc, p); });
-      SV d = chol6_solve_neg(jc.L0, p);
-      static_for<0, 3>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ulc, d, nullptr); });
-      L.q4(kLdsG + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
-      L.q4(kLdsG + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
-      static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, true>(jc, ulc, d, nullptr); });
-      L.q4(kLdsLam + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
-      L.q4(kLdsLam + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
-    };
+    // Contact-space operators by the inverse-articulated-inertia (Omega) recursion, ~2.4 k instructions where six
+    // unit-impulse recursions through the tree take ~4.0 k:
+    //   T = K = P_7 ... P_3 (columns by the unloaded down pass; LDS), G = Omega_pelvis K^T (LDS),
+    //   Lambda_own = Omega_foot (stays in registers: only the row set-up below reads it)
     auto t_column = [&](int i) {
       SV d;
 #pragma unroll
       for (int m = 0; m < 3; ++m) { d.w[m] = (i == m) ? 1.f : 0.f; d.v[m] = (i == m + 3) ? 1.f : 0.f; }
       static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, false>(jc, ul, d, nullptr); });
-      L.q4(kLdsT + i * 2 + 0) = make_float4(d.w[0], d.w[1], d.w[2], d.v[0]);
-      L.q4(kLdsT + i * 2 + 1) = make_float4(d.v[1], d.v[2], 0.f, 0.f);
+      L.q2(kLdsT + i * 3 + 0) = make_float2(d.w[0], d.w[1]);
+      L.q2(kLdsT + i * 3 + 1) = make_float2(d.w[2], d.v[0]);
+      L.q2(kLdsT + i * 3 + 2) = make_float2(d.v[1], d.v[2]);
     };
-#ifndef SS_UNIT_COLUMNS
-    // Omega recursion (default; -DSS_UNIT_COLUMNS selects the six unit-impulse recursions instead): ~2.4 k
-    // instructions instead of ~4.0 k.  Measured 0.1194 vs 0.1210 ms/step with three T columns per loop trip:
-    //   T = K = P_7 ... P_3 (columns by the unloaded down pass), G = Omega_pelvis K^T, Lambda_own = Omega_foot
 #ifndef SS_T_ILP
 #define SS_T_ILP 3   // measured 1 -> 0.1198, 2 -> 0.1197, 3 -> 0.1194 ms/step
 #endif
@@ -625,87 +606,49 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       t_column(i + 2 * (6 / SS_T_ILP));
 #endif
     }
-    {
-      OMG O;
-      {   // Omega_0 = (L L^T)^-1, column by column
-        float inv[6][6];
+    OMG O;
+    {   // Omega_0 = (L L^T)^-1, column by column
+      float inv[6][6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          SV e;
+      for (int i = 0; i < 6; ++i) {
+        SV e;
 #pragma unroll
-          for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? -1.f : 0.f; e.v[m] = (i == m + 3) ? -1.f : 0.f; }
-          SV x = chol6_solve_neg(jc.L0, e);
-          inv[0][i] = x.w[0]; inv[1][i] = x.w[1]; inv[2][i] = x.w[2]; inv[3][i] = x.v[0]; inv[4][i] = x.v[1]; inv[5][i] = x.v[2];
-        }
-        O.W.m[0] = inv[0][0]; O.W.m[1] = inv[1][1]; O.W.m[2] = inv[2][2]; O.W.m[3] = inv[0][1]; O.W.m[4] = inv[0][2]; O.W.m[5] = inv[1][2];
-        O.V.m[0] = inv[3][3]; O.V.m[1] = inv[4][4]; O.V.m[2] = inv[5][5]; O.V.m[3] = inv[3][4]; O.V.m[4] = inv[3][5]; O.V.m[5] = inv[4][5];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) O.X[a][b] = inv[a][3 + b];
+        for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? -1.f : 0.f; e.v[m] = (i == m + 3) ? -1.f : 0.f; }
+        SV x = chol6_solve_neg(jc.L0, e);
+        inv[0][i] = x.w[0]; inv[1][i] = x.w[1]; inv[2][i] = x.w[2]; inv[3][i] = x.v[0]; inv[4][i] = x.v[1]; inv[5][i] = x.v[2];
       }
-      static_for<0, 3>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
-      {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K)
-        float Wf[3][3], Vf[3][3], Kc[6][6];          // Kc[m][i] = K[i][m] = (T column m)[i]
-        sym_full(O.W, Wf);
-        sym_full(O.V, Vf);
+      O.W.m[0] = inv[0][0]; O.W.m[1] = inv[1][1]; O.W.m[2] = inv[2][2]; O.W.m[3] = inv[0][1]; O.W.m[4] = inv[0][2]; O.W.m[5] = inv[1][2];
+      O.V.m[0] = inv[3][3]; O.V.m[1] = inv[4][4]; O.V.m[2] = inv[5][5]; O.V.m[3] = inv[3][4]; O.V.m[4] = inv[3][5]; O.V.m[5] = inv[4][5];
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          float4 c0 = L.q4(kLdsT + m * 2 + 0), c1 = L.q4(kLdsT + m * 2 + 1);
-          Kc[m][0] = c0.x; Kc[m][1] = c0.y; Kc[m][2] = c0.z; Kc[m][3] = c0.w; Kc[m][4] = c1.x; Kc[m][5] = c1.y;
-        }
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const float n[3] = {Kc[0][i], Kc[1][i], Kc[2][i]}, f[3] = {Kc[3][i], Kc[4][i], Kc[5][i]};
-          float w[3], v[3];
+        for (int b = 0; b < 3; ++b) O.X[a][b] = inv[a][3 + b];
+    }
+    static_for<0, 3>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
+    {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K)
+      float Wf[3][3], Vf[3][3], Kc[6][6];          // Kc[m][i] = K[i][m] = (T column m)[i]
+      sym_full(O.W, Wf);
+      sym_full(O.V, Vf);
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            w[a] = Wf[a][0] * n[0] + Wf[a][1] * n[1] + Wf[a][2] * n[2] + O.X[a][0] * f[0] + O.X[a][1] * f[1] + O.X[a][2] * f[2];
-            v[a] = O.X[0][a] * n[0] + O.X[1][a] * n[1] + O.X[2][a] * n[2] + Vf[a][0] * f[0] + Vf[a][1] * f[1] + Vf[a][2] * f[2];
-          }
-          L.q4(kLdsG + i * 2 + 0) = make_float4(w[0], w[1], w[2], v[0]);
-          L.q4(kLdsG + i * 2 + 1) = make_float4(v[1], v[2], 0.f, 0.f);
-        }
+      for (int m = 0; m < 6; ++m) {
+        float2 c0 = L.q2(kLdsT + m * 3 + 0), c1 = L.q2(kLdsT + m * 3 + 1), c2 = L.q2(kLdsT + m * 3 + 2);
+        Kc[m][0] = c0.x; Kc[m][1] = c0.y; Kc[m][2] = c1.x; Kc[m][3] = c1.y; Kc[m][4] = c2.x; Kc[m][5] = c2.y;
       }
-      static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
-      {   // Lambda_own = Omega_foot, stored column-wise
-        float Wf[3][3], Vf[3][3];
-        sym_full(O.W, Wf);
-        sym_full(O.V, Vf);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          L.q4(kLdsLam + i * 2 + 0) = make_float4(Wf[0][i], Wf[1][i], Wf[2][i], O.X[i][0]);
-          L.q4(kLdsLam + i * 2 + 1) = make_float4(O.X[i][1], O.X[i][2], 0.f, 0.f);
-          L.q4(kLdsLam + (3 + i) * 2 + 0) = make_float4(O.X[0][i], O.X[1][i], O.X[2][i], Vf[0][i]);
-          L.q4(kLdsLam + (3 + i) * 2 + 1) = make_float4(Vf[1][i], Vf[2][i], 0.f, 0.f);
+      for (int i = 0; i < 6; ++i) {
+        const float n[3] = {Kc[0][i], Kc[1][i], Kc[2][i]}, f[3] = {Kc[3][i], Kc[4][i], Kc[5][i]};
+        float w[3], v[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          w[a] = Wf[a][0] * n[0] + Wf[a][1] * n[1] + Wf[a][2] * n[2] + O.X[a][0] * f[0] + O.X[a][1] * f[1] + O.X[a][2] * f[2];
+          v[a] = O.X[0][a] * n[0] + O.X[1][a] * n[1] + O.X[2][a] * n[2] + Vf[a][0] * f[0] + Vf[a][1] * f[1] + Vf[a][2] * f[2];
         }
+        L.q2(kLdsG + i * 3 + 0) = make_float2(w[0], w[1]);
+        L.q2(kLdsG + i * 3 + 1) = make_float2(w[2], v[0]);
+        L.q2(kLdsG + i * 3 + 2) = make_float2(v[1], v[2]);
       }
     }
-#else
-#pragma unroll 1
-    for (int i = 0; i < 6 / SS_LAM_ILP; ++i) {
-      float ul1[NH], ul2[NH];
-      unit_column(i, ul);
-#if SS_LAM_ILP >= 2
-      unit_column(i + 6 / SS_LAM_ILP, ul1);
-#endif
-#if SS_LAM_ILP >= 3
-      unit_column(i + 2 * (6 / SS_LAM_ILP), ul2);
-#endif
-      (void)ul1; (void)ul2;
-    }
-    // unit pelvis twists through the unloaded own leg: T columns
-#pragma unroll 1
-    for (int i = 0; i < 6 / SS_LAM_ILP; ++i) {
-      t_column(i);
-#if SS_LAM_ILP >= 2
-      t_column(i + 6 / SS_LAM_ILP);
-#endif
-#if SS_LAM_ILP >= 3
-      t_column(i + 2 * (6 / SS_LAM_ILP));
-#endif
-    }
-#endif
+    static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
     SS_PROF(7);
     // own-foot twist under the free velocities
     float V[6];
@@ -719,24 +662,29 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
     }
-    // rows -> LDS: per (corner, direction) 3 float4: y_own[6], dir[3], 1/A, b_n ; all-zero rows for inactive corners
-    static_for<0, 4>([&](auto Kc) {
-      constexpr int k = decltype(Kc)::value;
-      if (active & (1 << k)) {
+    // rows (registers): per (corner, direction) y_own[6] = Lambda_own w, dir[3], 1/A, b_n ; all-zero for inactive corners
+    float rY[12][6], rD[12][3], rIA[12], rB[4];
+    {
+      float LW[3][3], LV[3][3];
+      sym_full(O.W, LW);
+      sym_full(O.V, LV);
+      static_for<0, 4>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
+        const bool on = (active >> k) & 1;
         const int sl = (cslot >> (2 * k)) & 3;
         float n[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) n[i] = L.s(S_STN + sl * 3 + i);
+        for (int i = 0; i < 3; ++i) n[i] = on ? L.s(S_STN + sl * 3 + i) : (i == 2 ? 1.f : 0.f);
         float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
         float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
         t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
         float t2[3];
         cross(n, t1, t2);
         float corr = fmaxf(pen[k] - kSlop, 0.f);
-        const float bnv = fminf(kErp * corr * (1.0f / kH), kVcorrMax);
+        rB[k] = on ? fminf(kErp * corr * (1.0f / kH), kVcorrMax) : 0.f;
         static_for<0, 3>([&](auto Dc) {
-          constexpr int d = decltype(Dc)::value;
+          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
           const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
           float w[6];
 #pragma unroll
@@ -744,27 +692,23 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           w[0] = cy * w[5] - cz * w[4];
           w[1] = cz * w[3] - cx * w[5];
           w[2] = cx * w[4] - cy * w[3];
-          float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float y[6];
 #pragma unroll
-          for (int l = 0; l < 6; ++l) {
-            float4 c0 = L.q4(kLdsLam + l * 2 + 0), c1 = L.q4(kLdsLam + l * 2 + 1);
-            y[0] += c0.x * w[l]; y[1] += c0.y * w[l]; y[2] += c0.z * w[l]; y[3] += c0.w * w[l];
-            y[4] += c1.x * w[l]; y[5] += c1.y * w[l];
+          for (int a = 0; a < 3; ++a) {
+            y[a] = LW[a][0] * w[0] + LW[a][1] * w[1] + LW[a][2] * w[2] + O.X[a][0] * w[3] + O.X[a][1] * w[4] + O.X[a][2] * w[5];
+            y[3 + a] = O.X[0][a] * w[0] + O.X[1][a] * w[1] + O.X[2][a] * w[2] + LV[a][0] * w[3] + LV[a][1] * w[4] + LV[a][2] * w[5];
           }
           float A = 0.f;
 #pragma unroll
           for (int l = 0; l < 6; ++l) A += w[l] * y[l];
-          constexpr int row = kLdsRows + (k * 3 + d) * 3;
-          L.q4(row + 0) = make_float4(y[0], y[1], y[2], y[3]);
-          L.q4(row + 1) = make_float4(y[4], y[5], w[3], w[4]);
-          L.q4(row + 2) = make_float4(w[5], 1.0f / A, d == 0 ? bnv : 0.f, 0.f);
-        });
-      } else {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) L.q4(kLdsRows + k * 9 + i) = z;
-      }
-    });
+          for (int l = 0; l < 6; ++l) rY[row][l] = on ? y[l] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rD[row][c] = on ? w[3 + c] : 0.f;
+          rIA[row] = on ? 1.0f / A : 0.f;
+        });
+      });
+    }
     SS_PROF(8);
     // projected Gauss-Seidel on the own foot; Jacobi coupling to the other foot once per sweep
     float lam[4][3];
@@ -782,14 +726,12 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
         float fc[3] = {0.f, 0.f, 0.f};
         static_for<0, 3>([&](auto Dc) {
-          constexpr int d = decltype(Dc)::value;
-          constexpr int row = kLdsRows + (k * 3 + d) * 3;
-          float4 r0 = L.q4(row + 0), r1 = L.q4(row + 1), r2 = L.q4(row + 2);
+          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
           float px = Vv[0] + Vw[1] * cz - Vw[2] * cy;
           float py = Vv[1] + Vw[2] * cx - Vw[0] * cz;
           float pz = Vv[2] + Vw[0] * cy - Vw[1] * cx;
-          float vrel = r1.z * px + r1.w * py + r2.x * pz;
-          float ln = lam[k][d] + (r2.z - vrel) * r2.y;
+          float vrel = rD[row][0] * px + rD[row][1] * py + rD[row][2] * pz;
+          float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
           if constexpr (d == 0) {
             ln = fmaxf(ln, 0.f);
           } else {
@@ -798,9 +740,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           }
           float dl = ln - lam[k][d];
           lam[k][d] = ln;
-          Vw[0] += r0.x * dl; Vw[1] += r0.y * dl; Vw[2] += r0.z * dl;
-          Vv[0] += r0.w * dl; Vv[1] += r1.x * dl; Vv[2] += r1.y * dl;
-          fc[0] += r1.z * dl; fc[1] += r1.w * dl; fc[2] += r2.x * dl;
+          Vw[0] += rY[row][0] * dl; Vw[1] += rY[row][1] * dl; Vw[2] += rY[row][2] * dl;
+          Vv[0] += rY[row][3] * dl; Vv[1] += rY[row][4] * dl; Vv[2] += rY[row][5] * dl;
+          fc[0] += rD[row][0] * dl; fc[1] += rD[row][1] * dl; fc[2] += rD[row][2] * dl;
         });
         dW.v[0] += fc[0]; dW.v[1] += fc[1]; dW.v[2] += fc[2];
         dW.w[0] += cy * fc[2] - cz * fc[1];
@@ -813,17 +755,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       SV dp = zero;
 #pragma unroll
       for (int l = 0; l < 6; ++l) {
-        float4 c0 = L.q4(kLdsG + l * 2 + 0), c1 = L.q4(kLdsG + l * 2 + 1);
-        dp.w[0] += c0.x * dw[l]; dp.w[1] += c0.y * dw[l]; dp.w[2] += c0.z * dw[l];
-        dp.v[0] += c0.w * dw[l]; dp.v[1] += c1.x * dw[l]; dp.v[2] += c1.y * dw[l];
+        float2 c0 = L.q2(kLdsG + l * 3 + 0), c1 = L.q2(kLdsG + l * 3 + 1), c2 = L.q2(kLdsG + l * 3 + 2);
+        dp.w[0] += c0.x * dw[l]; dp.w[1] += c0.y * dw[l]; dp.w[2] += c1.x * dw[l];
+        dp.v[0] += c1.y * dw[l]; dp.v[1] += c2.x * dw[l]; dp.v[2] += c2.y * dw[l];
       }
       const SV dpo = xchg_sv(dp);
       const float dpv[6] = {dpo.w[0], dpo.w[1], dpo.w[2], dpo.v[0], dpo.v[1], dpo.v[2]};
 #pragma unroll
       for (int l = 0; l < 6; ++l) {
-        float4 c0 = L.q4(kLdsT + l * 2 + 0), c1 = L.q4(kLdsT + l * 2 + 1);
-        V[0] += c0.x * dpv[l]; V[1] += c0.y * dpv[l]; V[2] += c0.z * dpv[l];
-        V[3] += c0.w * dpv[l]; V[4] += c1.x * dpv[l]; V[5] += c1.y * dpv[l];
+        float2 c0 = L.q2(kLdsT + l * 3 + 0), c1 = L.q2(kLdsT + l * 3 + 1), c2 = L.q2(kLdsT + l * 3 + 2);
+        V[0] += c0.x * dpv[l]; V[1] += c0.y * dpv[l]; V[2] += c1.x * dpv[l];
+        V[3] += c1.y * dpv[l]; V[4] += c2.x * dpv[l]; V[5] += c2.y * dpv[l];
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) { W.w[i] += dW.w[i]; W.v[i] += dW.v[i]; }
