@@ -294,6 +294,20 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   SS_PROF(0);
   // LDS round trips (~100 cycles) are fully exposed with one wavefront per SIMD, and the compiler issues each
   // ds_read right before its use: batch the loads of a phase up front / prefetch one joint ahead instead.
+#ifndef SS_VEL_LDS      // body twists in registers (AGPR-parked by the compiler): 0.1095 vs 0.1113 ms/step through LDS
+  SV velr[13];
+#define SS_VEL_PUT(b, v) velr[(b) <= 8 ? (b) : (b) - 5] = v
+#define SS_VEL_GET(b) velr[(b) <= 8 ? (b) : (b) - 5]
+#else
+#define SS_VEL_PUT(b, v) vel_put<b>(L, v)
+#define SS_VEL_GET(b) vel_get<b>(L)
+#endif
+#ifdef SS_QDF_REGS
+  float qdfr[NH];
+#define SS_QDF(k) qdfr[k]
+#else
+#define SS_QDF(k) L.s(S_QDF + (k))
+#endif
   float qd_all[NH];
   {
     float q_all[NH];
@@ -316,7 +330,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       constexpr bool arm = j >= 13;
       SV v = xmotion<Model, j>(jc.r[k].cs, jc.r[k].sn, arm ? prev_arm : prev_leg);
       v.w[ax] += qd_all[k];
-      vel_put<b>(L, v);
+      SS_VEL_PUT(b, v);
       if constexpr (arm) prev_arm = v; else prev_leg = v;
     });
   }
@@ -330,7 +344,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   auto jin_load = [&](auto Ic) {
     constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1;
     JIn r;
-    r.vb = vel_get<b>(L);
+    r.vb = SS_VEL_GET(b);
     r.q = L.s(S_Q + k);
     r.a = L.s(S_ACT + k);
     return r;
@@ -450,7 +464,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   // ---- pass 3: accelerations -> free velocities (to LDS), leg and arm chains interleaved, twists prefetched
   {
     SV prev_leg = a0, prev_arm = a0;
-    auto vget = [&](auto Ic) { return vel_get<kOrderDown[decltype(Ic)::value] + 1>(L); };
+    auto vget = [&](auto Ic) { constexpr int b = kOrderDown[decltype(Ic)::value] + 1; return SS_VEL_GET(b); };
     SV vnext = vget(std::integral_constant<int, 0>{});
     static_for<0, NH>([&](auto Ic) {
       constexpr int idx = decltype(Ic)::value;
@@ -472,7 +486,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       float qdd = r.Dinv * (r.u - dotv);
       a.w[ax] += qdd;
       if constexpr (arm) prev_arm = a; else prev_leg = a;
-      L.s(S_QDF + k) = qd + h * qdd;
+      SS_QDF(k) = qd + h * qdd;
     });
   }
   float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
@@ -594,17 +608,12 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       L.q2(kLdsT + i * 3 + 2) = make_float2(d.v[1], d.v[2]);
     };
 #ifndef SS_T_ILP
-#define SS_T_ILP 3   // measured 1 -> 0.1198, 2 -> 0.1197, 3 -> 0.1194 ms/step
+#define SS_T_ILP 6   // all six T columns in one basic block; measured 1 -> 0.1114, 3 -> 0.1113, 6 -> 0.1108 ms/step
 #endif
 #pragma unroll 1
     for (int i = 0; i < 6 / SS_T_ILP; ++i) {
-      t_column(i);
-#if SS_T_ILP >= 2
-      t_column(i + 6 / SS_T_ILP);
-#endif
-#if SS_T_ILP >= 3
-      t_column(i + 2 * (6 / SS_T_ILP));
-#endif
+#pragma unroll
+      for (int m = 0; m < SS_T_ILP; ++m) t_column(i + m * (6 / SS_T_ILP));
     }
     OMG O;
     {   // Omega_0 = (L L^T)^-1, column by column
@@ -657,7 +666,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       static_for<0, 8>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         a = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, a);
-        a.w[kAxis[j]] += L.s(S_QDF + j);
+        a.w[kAxis[j]] += SS_QDF(j);
       });
 #pragma unroll
       for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
@@ -801,7 +810,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   {
     float qf[NH], qq[NH];
 #pragma unroll
-    for (int k = 0; k < NH; ++k) { qf[k] = L.s(S_QDF + k); qq[k] = L.s(S_Q + k); }
+    for (int k = 0; k < NH; ++k) { qf[k] = SS_QDF(k); qq[k] = L.s(S_Q + k); }
     SS_MEMBAR();
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
