@@ -672,7 +672,11 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
     }
     // rows (registers): per (corner, direction) y_own[6] = Lambda_own w, dir[3], 1/A, b_n ; all-zero for inactive corners
+#ifdef SS_PGS_TWIST_ROWS
+    float rY[12][6], rD[12][6], rIA[12], rB[4];     // rD = the full contact Jacobian row w = (c x dir, dir)
+#else
     float rY[12][6], rD[12][3], rIA[12], rB[4];
+#endif
     {
       float LW[3][3], LV[3][3];
       sym_full(O.W, LW);
@@ -712,8 +716,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           for (int l = 0; l < 6; ++l) A += w[l] * y[l];
 #pragma unroll
           for (int l = 0; l < 6; ++l) rY[row][l] = on ? y[l] : 0.f;
+#ifdef SS_PGS_TWIST_ROWS
+#pragma unroll
+          for (int c = 0; c < 6; ++c) rD[row][c] = on ? w[c] : 0.f;
+#else
 #pragma unroll
           for (int c = 0; c < 3; ++c) rD[row][c] = on ? w[3 + c] : 0.f;
+#endif
           rIA[row] = on ? 1.0f / A : 0.f;
         });
       });
@@ -730,6 +739,27 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       SV dW = zero;
       float* Vw = V;
       float* Vv = V + 3;
+#ifdef SS_PGS_TWIST_ROWS
+      static_for<0, 12>([&](auto Rc) {
+        constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
+        float vrel = rD[row][0] * V[0] + rD[row][1] * V[1] + rD[row][2] * V[2] + rD[row][3] * V[3] + rD[row][4] * V[4] +
+                     rD[row][5] * V[5];
+        float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
+        if constexpr (d == 0) {
+          ln = fmaxf(ln, 0.f);
+        } else {
+          float lim = mu * lam[k][0];
+          ln = fminf(fmaxf(ln, -lim), lim);
+        }
+        float dl = ln - lam[k][d];
+        lam[k][d] = ln;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) V[l] += rY[row][l] * dl;
+        dW.w[0] += rD[row][0] * dl; dW.w[1] += rD[row][1] * dl; dW.w[2] += rD[row][2] * dl;
+        dW.v[0] += rD[row][3] * dl; dW.v[1] += rD[row][4] * dl; dW.v[2] += rD[row][5] * dl;
+      });
+      (void)Vw; (void)Vv;
+#else
       static_for<0, 4>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
@@ -758,6 +788,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         dW.w[1] += cz * fc[0] - cx * fc[2];
         dW.w[2] += cx * fc[1] - cy * fc[0];
       });
+#endif
       // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
       // this foot through T
       const float dw[6] = {dW.w[0], dW.w[1], dW.w[2], dW.v[0], dW.v[1], dW.v[2]};
