@@ -13,10 +13,11 @@
 // The 4096-env workload therefore runs on 128 wavefronts of 32 envs and every serial chain (ABA sweeps, Lambda^-1
 // columns, contact rows, PGS) is half as long as with one env per lane.
 //
-// Per lane: 512 VGPR+AGPR and a private 2560-byte share of the CU's 160 KiB LDS (one wavefront per workgroup, no
-// barriers: lanes only read their own columns).  Region A (72 float4 slots, 16-byte lane stride, ds_*_b128):
-// 12 contact rows x 3, Lambda_own / G / T columns 3 x 6 x 2; the same bytes hold the 13 link twists during the
-// ABA.  Region B (scalars, element-major, ds_*_b32): actions, q, qd, free qd, base pose + twist, stones.
+// Per lane: up to 512 VGPR+AGPR and a private 640-byte share of LDS (40 KiB per wavefront, one wavefront per
+// workgroup, four workgroups = one per SIMD on a CU; no barriers: lanes only read their own columns).  Region A
+// (20 float4-slots): the contact operators G and T, 6 columns x 3 float2 items each, 8-byte lane stride (ds_*_b64).
+// Region B (scalars, element-major, ds_*_b32): actions, q, qd, free qd, base pose + twist, stones.  The link twists,
+// the 12 joint records, the 12 PGS rows and Lambda_own live in registers (the compiler parks them in AGPRs).
 #pragma once
 #include "ss_math.hpp"
 
