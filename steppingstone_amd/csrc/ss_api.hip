@@ -34,6 +34,7 @@ struct ss_env {
   int device;
   float* prob_shared;   // [121]
   float* prob_env;      // [121][npad] or null
+  float* obs_rows;      // [n][60] scratch: current observation rows for create_temp_states
 };
 
 namespace {
@@ -134,6 +135,7 @@ void ss_destroy(ss_env* env) {
   if (env->P.terrain) (void)hipFree(env->P.terrain);
   if (env->prob_shared) (void)hipFree(env->prob_shared);
   if (env->prob_env) (void)hipFree(env->prob_env);
+  if (env->obs_rows) (void)hipFree(env->obs_rows);
   if (env->P.prof) (void)hipFree(env->P.prof);
   delete env;
 }
@@ -232,12 +234,14 @@ int ss_set_auto_reset(ss_env* env, int32_t on) {
 int ss_create_temp_states(ss_env* env, float* out, void* stream) {
   if (!env || !out) return fail(SS_ERR_INVALID, "null argument");
   SS_HIP(hipSetDevice(env->device));
-  const int total = env->P.n * SS_NCELL;
-  dim3 grid((total + 255) / 256), block(256);
+  if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0) return fail(SS_ERR_INVALID, "out must be 16-byte aligned");
+  if (!env->obs_rows) SS_HIP(hipMalloc(&env->obs_rows, sizeof(float) * SS_OBS_DIM * (size_t)env->P.npad));
   if (env->kind == SS_WALKER3D)
-    hipLaunchKernelGGL((ss::temp_states_kernel<ss::ModelWalker3D>), grid, block, 0, (hipStream_t)stream, env->P, out);
+    hipLaunchKernelGGL((ss::obs_kernel<ss::ModelWalker3D>), grid64(env), dim3(ss::kWave), 0, (hipStream_t)stream, env->P, env->obs_rows);
   else
-    hipLaunchKernelGGL((ss::temp_states_kernel<ss::ModelMike>), grid, block, 0, (hipStream_t)stream, env->P, out);
+    hipLaunchKernelGGL((ss::obs_kernel<ss::ModelMike>), grid64(env), dim3(ss::kWave), 0, (hipStream_t)stream, env->P, env->obs_rows);
+  hipLaunchKernelGGL(ss::temp_states_kernel, dim3(env->P.n), dim3(ss::kTempThreads), 0, (hipStream_t)stream, env->P,
+                     (const float*)env->obs_rows, out);      // one workgroup per env
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
