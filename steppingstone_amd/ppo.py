@@ -107,13 +107,24 @@ class PPO:
     """algorithms/ppo.py:6-108 on device tensors (defaults of playground/train.py:72-82)."""
 
     def __init__(self, ac, clip_param=0.2, ppo_epoch=10, mini_batch_size=1024, value_loss_coef=1.0, entropy_coef=0.0,
-                 lr=3e-4, eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None):
+                 lr=3e-4, eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None,
+                 use_graph=False):
         self.ac = ac
         self.clip_param, self.ppo_epoch, self.mini_batch_size = clip_param, ppo_epoch, mini_batch_size
         self.value_loss_coef, self.entropy_coef, self.max_grad_norm = value_loss_coef, entropy_coef, max_grad_norm
         self.use_clipped_value_loss = use_clipped_value_loss
-        self.mirror_indices = mirror_indices
-        self.optimizer = torch.optim.Adam(ac.parameters(), lr=lr, eps=eps)
+        dev = next(ac.parameters()).device
+        # index lists on the parameters' device once: no host-to-device copies inside the (capturable) minibatch step
+        self.mirror_indices = None if mirror_indices is None else [
+            torch.as_tensor(i, dtype=torch.long, device=dev) for i in mirror_indices]
+        # use_graph: the minibatch step (gather, forward, backward, clip, Adam) is ~90 small launches; captured once
+        # in a hipGraph it replays as one submission.  Needs CUDA/HIP parameters and a single rank.
+        self.use_graph = bool(use_graph) and dev.type == "cuda"
+        if self.use_graph:
+            self.optimizer = torch.optim.Adam(ac.parameters(), lr=torch.tensor(float(lr), device=dev), eps=eps, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(ac.parameters(), lr=lr, eps=eps)
+        self._graph, self._warm, self._static = None, 0, None
 
     def _allreduce_grads(self):
         """Data-parallel learner: one RCCL all-reduce of the flattened gradient per minibatch (no-op on one rank)."""
@@ -131,7 +142,10 @@ class PPO:
 
     def set_lr(self, lr):
         for g in self.optimizer.param_groups:
-            g["lr"] = lr
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(float(lr))
+            else:
+                g["lr"] = lr
 
     def step_minibatch(self, obs, act, value_preds, returns, old_logp, adv):
         if self.mirror_indices is not None:
@@ -146,21 +160,62 @@ class PPO:
         self.optimizer.step()
         return vl.detach(), al.detach(), ent.detach()
 
+    # -- hipGraph path ------------------------------------------------------------------------------------------------
+    def _graph_ok(self):
+        import torch.distributed as dist
+        return self.use_graph and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def _gathered_step(self, data, idx):
+        return self.step_minibatch(*(t[idx] for t in data))
+
+    def _graph_step(self, data, idx, refresh=True):
+        """data: the six flat rollout tensors of this update (copied into static storage when refresh is set, i.e.
+        once per update); idx: minibatch indices."""
+        if self._static is None:
+            self._static = (tuple(torch.empty_like(t) for t in data), torch.zeros_like(idx), torch.zeros(3, device=idx.device))
+            refresh = True
+        sdata, sidx, sout = self._static
+        if refresh:
+            for dst, src in zip(sdata, data):
+                dst.copy_(src)
+        if self._graph is None:
+            self._warm += 1
+            if self._warm <= 3:                         # eager warm-up steps on a side stream (real data, real steps)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    out = self._gathered_step(data, idx)
+                torch.cuda.current_stream().wait_stream(side)
+                return torch.stack(out)
+            self.optimizer.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._gathered_step(sdata, sidx)
+                sout.copy_(torch.stack(out))
+            self._graph = g
+        sidx.copy_(idx)
+        self._graph.replay()
+        return sout.clone()
+
     def update(self, roll):
         adv = roll.returns[:-1] - roll.value_preds[:-1]
         adv = (adv - adv.mean()) / (adv.std() + 1e-5)
         T, N = roll.rewards.shape[:2]
         flat = lambda t: t.reshape(T * N, -1)   # noqa: E731
-        obs, act = flat(roll.obs[:-1]), flat(roll.actions)
-        vp, ret, lp, adv = flat(roll.value_preds[:-1]), flat(roll.returns[:-1]), flat(roll.logp), flat(adv)
-        stats = torch.zeros(3, device=obs.device)
+        data = (flat(roll.obs[:-1]), flat(roll.actions), flat(roll.value_preds[:-1]), flat(roll.returns[:-1]),
+                flat(roll.logp), flat(adv))
+        dev = data[0].device
+        graph = self._graph_ok() and (T * N) % self.mini_batch_size == 0
+        stats = torch.zeros(3, device=dev)
         count = 0
         for _ in range(self.ppo_epoch):
-            perm = torch.randperm(T * N, device=obs.device)
+            perm = torch.randperm(T * N, device=dev)
             for s in range(0, T * N, self.mini_batch_size):
                 idx = perm[s:s + self.mini_batch_size]
-                out = self.step_minibatch(obs[idx], act[idx], vp[idx], ret[idx], lp[idx], adv[idx])
-                stats += torch.stack(out)
+                if graph:
+                    stats += self._graph_step(data, idx, refresh=(count == 0))
+                else:
+                    stats += torch.stack(self._gathered_step(data, idx))
                 count += 1
         return (stats / max(count, 1)).tolist()
 
@@ -194,10 +249,11 @@ class Rollouts:
             self.value_preds[-1] = next_value
 
 
-def collect(envs, ac, roll, num_steps, ep_returns):
+def collect(envs, ac, roll, num_steps, ep_returns=None, ep_stats=None):
     """The rollout loop of playground/train.py:363-469 with tensorised bookkeeping.  `envs` returns device tensors
-    (SteppingStoneVecEnv(return_numpy=False) or ShardedVecEnv).  Finished episodes' returns are appended to
-    ep_returns (a list of tensors)."""
+    (SteppingStoneVecEnv(return_numpy=False) or ShardedVecEnv).  Finished episodes are reported either through
+    ep_stats, a device tensor [2] accumulating (sum of returns, count) with no host synchronisation (the form a
+    hipGraph can capture), or appended to the list ep_returns (one host sync per step)."""
     for _ in range(num_steps):
         with torch.no_grad():
             value, action, logp = ac.act(roll.obs[roll.step])
@@ -205,9 +261,42 @@ def collect(envs, ac, roll, num_steps, ep_returns):
         d = done.to(torch.float32).unsqueeze(1)
         mask = 1.0 - d
         bad_mask = 1.0 - info["bad_transition"].to(torch.float32).unsqueeze(1)
-        if bool(done.any()):
+        if ep_stats is not None:
+            ep_stats[0] += (info["ep_ret"] * d[:, 0]).sum()
+            ep_stats[1] += d.sum()
+        elif ep_returns is not None and bool(done.any()):
             ep_returns.append(info["ep_ret"][done].clone())
         roll.insert(obs, action, logp, value, rew.unsqueeze(1), mask, bad_mask)
+
+
+class GraphedCollector:
+    """collect() captured once in a hipGraph (policy inference, env step kernel, storage writes of all num_steps
+    steps: ~50 launches per step) and replayed per update.  The rollout storage, the env's I/O buffers and the
+    episode accumulators are static, and every call starts at roll.step == 0, so all addresses are replay-stable."""
+
+    def __init__(self, envs, ac, roll, num_steps):
+        self.envs, self.ac, self.roll, self.num_steps = envs, ac, roll, num_steps
+        self.ep_stats = torch.zeros(2, device=roll.obs.device)
+        self.graph, self.warm = None, 0
+
+    def __call__(self):
+        assert self.roll.step == 0 and self.num_steps == self.roll.rewards.shape[0]
+        self.ep_stats.zero_()
+        if self.graph is None:
+            if self.warm < 1:                              # one eager rollout on a side stream first
+                self.warm += 1
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats)
+                torch.cuda.current_stream().wait_stream(side)
+                return self.ep_stats
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats)
+            self.graph = g
+        self.graph.replay()
+        return self.ep_stats
 
 
 def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_threshold=0.85, events=5, max_steps=400):
@@ -241,27 +330,44 @@ def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_thres
 
 
 def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curriculum=True, use_mirror=False, lr=3e-4,
-          gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print):
-    """Fixed-order-curriculum PPO (playground/train.py:115-118,211-222,503-521).  Returns the list of per-update stats."""
+          gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto"):
+    """Fixed-order-curriculum PPO (playground/train.py:115-118,211-222,503-521).  Returns the list of per-update stats.
+    use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs, and the episode
+    statistics stay on the device (mean return of the episodes finished during the update, carried over when none
+    finished) instead of the reference's host-side deque."""
+    import torch.distributed as dist
     torch.manual_seed(seed)
     dev = envs.device if hasattr(envs, "device") else envs.local.device
+    dev = torch.device(dev)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if use_graph == "auto":
+        use_graph = dev.type == "cuda" and not multi
     ac = ActorCritic(num_ensembles=num_ensembles).to(dev)
     mirror = envs.get_mirror_indices() if use_mirror and hasattr(envs, "get_mirror_indices") else None
-    agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror)
+    agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=use_graph)
     n = envs.num_envs
     roll = Rollouts(num_steps, n, dev)
     curriculum = 0
     if use_curriculum:
         envs.update_curriculum(curriculum)
     roll.obs[0].copy_(envs.reset())
+    collector = GraphedCollector(envs, ac, roll, num_steps) if use_graph else None
     recent, history, start = [], [], time.time()
+    mean_ret = float("nan")
     for j in range(num_updates):
         agent.set_lr(harness.exponential_decay(j, 0.99, lr, 3e-5))
-        ep = []
-        collect(envs, ac, roll, num_steps, ep)
-        recent = (recent + ep)[-50:]
-        mean_ret = float(torch.cat(recent).mean()) if recent else float("nan")
-        if use_curriculum and recent and mean_ret > 1000 and curriculum <= 4:
+        if collector is not None:
+            ssum, cnt = collector().tolist()               # the one host sync of the rollout
+            if cnt > 0:
+                mean_ret = ssum / cnt
+            have = not math.isnan(mean_ret)
+        else:
+            ep = []
+            collect(envs, ac, roll, num_steps, ep)
+            recent = (recent + ep)[-50:]
+            mean_ret = float(torch.cat(recent).mean()) if recent else float("nan")
+            have = bool(recent)
+        if use_curriculum and have and mean_ret > 1000 and curriculum <= 4:
             curriculum += 1
             envs.update_curriculum(curriculum)
         with torch.no_grad():

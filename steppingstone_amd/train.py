@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--mini-batch-size", type=int, default=1024)     # playground/train.py:62
     ap.add_argument("--no-curriculum", action="store_true")
     ap.add_argument("--mirror", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run rollout and minibatch steps eagerly (no hipGraph)")
     ap.add_argument("--save", default="")
     args = ap.parse_args()
 
@@ -49,7 +50,8 @@ def main():
 
     ac, hist = ppo.train(envs, args.updates, num_steps=args.num_steps, num_ensembles=args.num_ensembles, seed=args.seed,
                          use_curriculum=not args.no_curriculum, use_mirror=args.mirror, ppo_epoch=args.ppo_epoch,
-                         mini_batch_size=args.mini_batch_size, log=log)
+                         mini_batch_size=args.mini_batch_size, log=log,
+                         use_graph=False if args.no_graph else "auto")
     if args.save and rank == 0:
         torch.save(ac.state_dict(), args.save)
     if world > 1:
