@@ -335,7 +335,9 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
       a = 2.f * u01(bits) - 1.f;
     } else {
-      a = fminf(fmaxf(io.act[(size_t)e * NJ + gj], -1.f), 1.f);
+      const float x = io.act[(size_t)e * NJ + gj];
+      a = fminf(fmaxf(x, -1.f), 1.f);
+      a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
     }
     L.s(S_ACT + k) = sg * a;
   });

@@ -402,3 +402,53 @@ def test_ppo_graph_replay_matches_eager():
     # the sampling noise differs between the eager and the replayed generator offsets, so compare what does not depend
     # on it: shapes, finiteness and the first observation row (reset state); then require exact replay determinism
     assert stores[0][0].shape == stores[1][0].shape and torch.isfinite(stores[1][0]).all() and torch.isfinite(stores[1][1]).all()
+
+
+def test_large_batch_is_a_union_of_small_ones():
+    """Maximum-size property (131072 envs = 4096 wavefronts, four per CU): every env's trajectory is keyed by its
+    global id only, so a 64-env instance created at env_id_offset=k reproduces envs [k, k+64) of the big batch
+    bit for bit -- across wavefront placement, occupancy and batch size."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    big = SteppingStoneVecEnv("MikeStepperEnv-v0", 131072, seed=21, device="cuda:0", return_numpy=False)
+    big.update_curriculum(5)
+    big.reset()
+    for t in range(6):
+        ob, rb, db = big.rollout_random(1, t0=t)
+    assert torch.isfinite(ob).all() and torch.isfinite(rb).all()
+    for k in (0, 70000, 131072 - 64):
+        small = SteppingStoneVecEnv("MikeStepperEnv-v0", 64, seed=21, device="cuda:0", env_id_offset=k, return_numpy=False)
+        small.update_curriculum(5)
+        small.reset()
+        for t in range(6):
+            osm, rsm, dsm = small.rollout_random(1, t0=t)
+        assert torch.equal(osm, ob[k:k + 64]) and torch.equal(rsm, rb[k:k + 64]) and torch.equal(dsm, db[k:k + 64])
+        small.close()
+    big.close()
+
+
+def test_non_finite_and_out_of_range_actions_are_contained():
+    """PHYSICS.md 4.8 / 2: actions are clipped to [-1,1] (so is +-Inf) and a NaN action may not poison the state: the
+    episode ends (done, zero reward), the env auto-resets, every output stays finite, neighbours are unaffected, and the
+    oracle makes the same decisions."""
+    n = 64
+    g = gpu_env("Walker3DStepperEnv-v0", n, seed=12)
+    o = ol.OracleEnv("walker3d", n, seed=12)
+    assert np.abs(g.reset() - o.reset()).max() < 1e-6
+    a = o.random_actions(0).copy()
+    a[3, 5] = np.nan
+    a[7, :] = np.inf
+    a[9, 2] = -np.inf
+    a[11, :] = 50.0            # far out of range: clipped, not an error
+    og, rg, dg, _ = g.step(a)
+    oo, ro, do, _ = o.step(a)
+    assert np.isfinite(og).all() and np.isfinite(rg).all()
+    assert np.array_equal(dg, do)
+    assert dg[3] and not dg[7] and not dg[9] and not dg[11]      # NaN ends the episode; +-Inf and 50 are clipped to +-1
+    assert rg[3] == 0.0
+    assert np.abs(og - oo).max() < 2e-3
+    # the following step runs normally for everyone (the poisoned envs were reset)
+    a2 = o.random_actions(1)
+    og, rg, dg, _ = g.step(a2)
+    oo, ro, do, _ = o.step(a2)
+    assert np.isfinite(og).all() and np.abs(og - oo).max() < 2e-3
+    g.close()
