@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step all-gather")
     args = ap.parse_args()
 
+    # more hardware queues than HIP's default 4, so that RCCL's stream never shares one with the launch stream
+    # (steppingstone_amd/distributed.py); must be set before the HIP runtime starts
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from steppingstone_amd.distributed import ShardedVecEnv

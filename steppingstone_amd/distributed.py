@@ -13,6 +13,7 @@ import torch.distributed as dist
 from ._lib import ACT_DIM, OBS_DIM
 
 PACK = OBS_DIM + 2
+DEPTH = 8
 
 
 class ShardedVecEnv:
@@ -26,14 +27,26 @@ class ShardedVecEnv:
         # SS_FORCE_COLLECTIVE=1 issues the all-gather even at world size 1 (exercises the RCCL path on a 1-GPU box)
         self._collective = self.world > 1 or (dist.is_initialized() and os.environ.get("SS_FORCE_COLLECTIVE") == "1")
         self.n_local = int(local_env.num_envs)
+        if self._collective and torch.device(local_env.device).type == "cuda":
+            # HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) round robin, and the first
+            # stream taken from PyTorch's pool lands on the default stream's queue: if that is RCCL's stream, the
+            # all-gather cannot run under the step kernel (measured +26 us per 0.11 ms step instead of +9 us,
+            # tools/gather_queue_probe.py).  Take and use one pool stream before the first collective.
+            self._spare_stream = torch.cuda.Stream(device=local_env.device)
+            with torch.cuda.stream(self._spare_stream):
+                torch.zeros(8, device=local_env.device).add_(1)
+            self._spare_stream.synchronize()
         self.num_envs = self.n_local * self.world
         self.observation_space = getattr(local_env, "observation_space", None)
         self.action_space = getattr(local_env, "action_space", None)
         dev = local_env.device
-        # double-buffered: the all-gather of step t overlaps the kernel of step t+1 in the rollout benchmark
-        self._packed = [torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
-        self._gathered = [torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
-        self._work = [None, None]
+        # ring of DEPTH buffers: the all-gather of step t runs under the kernels of steps t+1.. and the launch stream
+        # waits on the collectives once per DEPTH steps, as one batch.  Measured on one rank with the collective forced:
+        # a cross-stream wait before every kernel (any depth) costs +26 us per 0.11 ms step, batched waits every 8
+        # steps +7 us; a hipGraph of the 8 steps is slower (+13 us) (tools/gather_overhead.py, gather_graph_probe.py).
+        self._packed = [torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+        self._gathered = [torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
+        self._work = [None] * DEPTH
 
     # -- helpers
     def local_slice(self):
@@ -77,16 +90,18 @@ class ShardedVecEnv:
 
     def rollout_random(self, num_steps, t0=0, gather=True):
         """Benchmark path: each of num_steps steps = one local kernel launch writing the packed block + (when
-        gather) one asynchronous all-gather of it, overlapped with the next step's kernel."""
+        gather) one asynchronous all-gather of it, overlapped with the following steps' kernels."""
         slot = 0
         for k in range(num_steps):
-            slot = k & 1
-            self._wait(slot)                       # the buffer's previous all-gather (two steps ago) must be done
+            slot = k % DEPTH
+            if slot == 0:                          # buffers come round again: all DEPTH collectives must be done.
+                for i in range(DEPTH):             # Waits are issued as one batch so that the DEPTH kernels between
+                    self._wait(i)                  # two batches are dispatched back to back
             self.local.step_packed(self._packed[slot], actions=None, t=t0 + k)
             if gather:
                 self._gather_packed(slot, async_op=True)
-        self._wait(0)
-        self._wait(1)
+        for i in range(DEPTH):
+            self._wait(i)
         g = self._gathered[slot] if (gather and self._collective) else self._packed[slot]
         return self._split(g)
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--save", default="")
     args = ap.parse_args()
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # see steppingstone_amd/distributed.py (RCCL stream vs launch stream)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

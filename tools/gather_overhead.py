@@ -20,13 +20,14 @@ for gather in (False, True, False, True):
     t0 = time.perf_counter()
     slot = 0
     for k in range(K):
-        slot = k & 1
-        env._wait(slot)
+        slot = k % len(env._packed)
+        if slot == 0:
+            for i in range(len(env._packed)): env._wait(i)
         env.local.step_packed(env._packed[slot], actions=None, t=k)
         if gather:
             env._gather_packed(slot, async_op=True)
     t1 = time.perf_counter()
-    env._wait(0); env._wait(1)
+    for i in range(len(env._packed)): env._wait(i)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     if dist.get_rank() == 0:
