@@ -42,7 +42,7 @@ def recorded_traffic(n_envs):
         return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (a port of docs/PHYSICS.md, NOT PyBullet) on the host cores, same workload, bounded."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -59,7 +59,7 @@ def cpu_baseline(seconds_budget=12.0):
         env.step(acts[steps % 4])
         steps += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or steps >= 200:
+        if el > seconds_budget or steps >= 400:
             break
     return {"value": ENVS_PER_GPU * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d control steps of %d Walker3D envs, oracle/ss_oracle.c fp32, OpenMP over %d host threads, "
@@ -151,8 +151,22 @@ def main():
                          "traffic_source": traffic_src,
                          "kernel": "ss::step_kernel<ModelWalker3D,true>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
-                         "note": "latency/VALU-bound per-lane rigid-body dynamics, not HBM-bound (DESIGN.md)"},
+                         "note": "VALU-issue-bound per-lane rigid-body dynamics (80 % VALU-busy, one wavefront per SIMD), not HBM-bound (DESIGN.md 4.1)"},
         }
+        if world == 1 and not use_dist and n_local < 32768:
+            # not the metric: the same kernel with every SIMD of the chip occupied (4 wavefronts per CU)
+            big = SteppingStoneVecEnv(args.env, 32768, seed=0, device=dev, return_numpy=False)
+            big.reset()
+            big.rollout_random(50, 0)
+            torch.cuda.synchronize(dev)
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record(); big.rollout_random(200, 50); b1.record()
+            torch.cuda.synchronize(dev)
+            bms = b0.elapsed_time(b1) / 200
+            out["capacity"] = {"envs_per_gpu": 32768, "ms_per_step": bms, "value": 32768 / (bms * 1e-3), "unit": "env-steps/s",
+                               "roofline_frac": ALGO_BYTES_PER_ENV_STEP * 32768 / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "same kernel at 32768 envs on this GPU (all 1024 SIMDs occupied); not the BASELINE config"}
+            big.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
