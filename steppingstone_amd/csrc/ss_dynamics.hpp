@@ -393,7 +393,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     JRec& r = jc.r[k];
     r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
     r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
-    r.Dinv = 1.0f / (r.Uw[ax] + Dadd);
+    r.Dinv = SS_RCP(r.Uw[ax] + Dadd);
     r.u = tau - pA.w[ax];
     const float* Uw = r.Uw;
     const float* Uv = r.Uv;
@@ -724,7 +724,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) rD[row][c] = on ? w[3 + c] : 0.f;
 #endif
-          rIA[row] = on ? 1.0f / A : 0.f;
+          rIA[row] = on ? SS_RCP(A) : 0.f;
         });
       });
     }

@@ -28,6 +28,17 @@
 // hides a value from CSE so that address arithmetic is redone after a long region instead of being kept live
 #define SS_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SS_RSQRT(x) rsqrtf(x)
+// reciprocal: v_rcp_f32 (1 ulp) + one Newton step = 3 VALU instructions where the IEEE division expands to ~10
+// (24 of them per substep: joint 1/D and contact-row 1/A).  -DSS_IEEE_DIV restores the division.
+#ifdef SS_IEEE_DIV
+#define SS_RCP(x) (1.0f / (x))
+#else
+static __device__ __forceinline__ float ss_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+#define SS_RCP(x) ss_rcp(x)
+#endif
 #define SS_UMULHI(a, b) __umulhi((a), (b))
 #define SS_F2U(x) __float_as_uint(x)
 #else
@@ -40,6 +51,7 @@ static inline unsigned ss_host_f2u(float x) { unsigned u; std::memcpy(&u, &x, 4)
 #define SS_FENCE() ((void)0)
 #define SS_OPAQUE(x) asm volatile("" : "+r"(x))
 #define SS_RSQRT(x) ss_host_rsqrt(x)
+#define SS_RCP(x) (1.0f / (x))
 #define SS_UMULHI(a, b) ss_host_umulhi((a), (b))
 #define SS_F2U(x) ss_host_f2u(x)
 #endif
