@@ -14,13 +14,16 @@ LIB = os.path.join(LIBDIR, "libsteppingstone.so")
 SOURCES = ["ss_api.hip"]
 HEADERS = ["ss_math.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "ss_model_tables.hpp",
            os.path.join("..", "..", "include", "steppingstone.h")]
-# IEEE -O3 without the SLP vectorizer.  Measured in round 1 on gfx950 / ROCm 7.2 (tools/gpu_debug2.py):
-#   * with SLP vectorisation (packed v_pk_fma_f32 / v_pk_mul_f32) the 28k-instruction step kernel is MISCOMPILED at
-#     -O2/-O3 (wrong and run-to-run varying results); -O1 and -O3 -fno-slp-vectorize match the oracle to 2e-7;
-#   * -fno-signed-zeros triggers the same failure even at plain -O3;
-#   * packed f32 VALU is not a throughput win on gfx950 anyway (MI355X_MICROARCH.md, per-instruction constants).
-# No fast-math family flags: -ffinite-math-only would delete the non-finite guard of PHYSICS.md 4.8.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize"]
+# -O3 without the SLP vectorizer, signed zeros not honoured.  Measured on gfx950 / ROCm 7.2:
+#   * SLP vectorisation (packed v_pk_fma_f32 / v_pk_mul_f32) miscompiled the 1-env-per-lane kernel of v1-v3 (wrong,
+#     run-to-run varying results next to KBs of scratch); the current kernel passes parity with it but is 30 %
+#     slower (aligned register pairs -> 536 B/lane of scratch): -fno-slp-vectorize stays;
+#   * -fno-signed-zeros lets the compiler drop the "+ 0" of zero-initialised accumulators and fold x*y+0 into a
+#     multiply: 0.1068 -> 0.1026 ms/step, all GPU parity tests green (it had triggered the v1-v3 miscompile too, so
+#     it is re-validated by the full GPU suite on every build change);
+#   * -fassociative-math would give another 1.5 % but re-orders the sums of the spec: not used.
+# No other fast-math flags: -ffinite-math-only would delete the non-finite guard of PHYSICS.md 4.8.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-fno-signed-zeros"]
 
 def hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
