@@ -682,6 +682,62 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
     }
+#ifdef SS_PGS_PACKED
+    // rows (registers, float pairs): per (corner, direction) y = Lambda_own w and the Jacobian row w = (c x dir, dir),
+    // 1/A, b_n.  Inactive corners keep finite rows (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
+    ssf2 rYp[12][3], rWp[12][3];
+    float rIA[12], rB[4];
+    {
+      float LW[3][3], LV[3][3];
+      sym_full(O.W, LW);
+      sym_full(O.V, LV);
+      ssf2 Lc[6][3];                     // column b of Lambda_own = [[W, X], [X^T, V]] as three pairs
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        Lc[b][0] = ssf2{LW[0][b], LW[1][b]}; Lc[b][1] = ssf2{LW[2][b], O.X[b][0]}; Lc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
+        Lc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Lc[3 + b][1] = ssf2{O.X[2][b], LV[0][b]}; Lc[3 + b][2] = ssf2{LV[1][b], LV[2][b]};
+      }
+      static_for<0, 4>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
+        const bool on = (active >> k) & 1;
+        const int sl = (cslot >> (2 * k)) & 3;
+        float n[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) n[i] = on ? L.s(S_STN + sl * 3 + i) : (i == 2 ? 1.f : 0.f);
+        float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+        float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+        t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
+        float t2[3];
+        cross(n, t1, t2);
+        float corr = fmaxf(pen[k] - kSlop, 0.f);
+        rB[k] = on ? fminf(kErp * corr * (1.0f / kH), kVcorrMax) : 0.f;
+        static_for<0, 3>([&](auto Dc) {
+          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
+          const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
+          float w[6];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) w[3 + c] = Rf[0][c] * dir[0] + Rf[1][c] * dir[1] + Rf[2][c] * dir[2];
+          w[0] = cy * w[5] - cz * w[4];
+          w[1] = cz * w[3] - cx * w[5];
+          w[2] = cx * w[4] - cy * w[3];
+          ssf2 y[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) y[i] = Lc[0][i] * ssf2{w[0], w[0]};
+#pragma unroll
+          for (int b = 1; b < 6; ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) y[i] = Lc[b][i] * ssf2{w[b], w[b]} + y[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { rYp[row][i] = y[i]; rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]}; }
+          ssf2 acc = rWp[row][0] * y[0];
+          acc = rWp[row][1] * y[1] + acc;
+          acc = rWp[row][2] * y[2] + acc;
+          rIA[row] = on ? SS_RCP(acc.x + acc.y) : 0.f;
+        });
+      });
+    }
+#else
     // rows (registers): per (corner, direction) y_own[6] = Lambda_own w, dir[3], 1/A, b_n ; all-zero for inactive corners
 #ifdef SS_PGS_TWIST_ROWS
     float rY[12][6], rD[12][6], rIA[12], rB[4];     // rD = the full contact Jacobian row w = (c x dir, dir)
@@ -738,6 +794,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         });
       });
     }
+#endif   // SS_PGS_PACKED rows
     SS_PROF(8);
 #ifdef SS_PGS_PACKED
     // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
@@ -748,11 +805,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     constexpr float mu = Model::friction;
     ssf2 Vp[3] = {{V[0], V[1]}, {V[2], V[3]}, {V[4], V[5]}};
     ssf2 Wp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    ssf2 rYp[12][3], rWp[12][3];
-#pragma unroll
-    for (int r = 0; r < 12; ++r)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { rYp[r][i] = ssf2{rY[r][2 * i], rY[r][2 * i + 1]}; rWp[r][i] = ssf2{rD[r][2 * i], rD[r][2 * i + 1]}; }
 #pragma unroll 1
     for (int it = 0; it < kPgsIters; ++it) {
       ssf2 dWp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
