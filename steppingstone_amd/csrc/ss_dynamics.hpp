@@ -645,10 +645,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         for (int b = 0; b < 3; ++b) O.X[a][b] = inv[a][3 + b];
     }
     static_for<0, 3>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
-    {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K)
-      float Wf[3][3], Vf[3][3], Kc[6][6];          // Kc[m][i] = K[i][m] = (T column m)[i]
+    {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K); packed f32
+      float Wf[3][3], Vf[3][3];
       sym_full(O.W, Wf);
       sym_full(O.V, Vf);
+      ssf2 Oc[6][3];                     // column b of Omega_pelvis = [[W, X], [X^T, V]] as three pairs
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        Oc[b][0] = ssf2{Wf[0][b], Wf[1][b]}; Oc[b][1] = ssf2{Wf[2][b], O.X[b][0]}; Oc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
+        Oc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Oc[3 + b][1] = ssf2{O.X[2][b], Vf[0][b]}; Oc[3 + b][2] = ssf2{Vf[1][b], Vf[2][b]};
+      }
+      float Kc[6][6];                    // Kc[m][i] = K[i][m] = (T column m)[i]
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         float2 c0 = L.q2(kLdsT + m * 3 + 0), c1 = L.q2(kLdsT + m * 3 + 1), c2 = L.q2(kLdsT + m * 3 + 2);
@@ -656,16 +663,15 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const float n[3] = {Kc[0][i], Kc[1][i], Kc[2][i]}, f[3] = {Kc[3][i], Kc[4][i], Kc[5][i]};
-        float w[3], v[3];
+        ssf2 g[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          w[a] = Wf[a][0] * n[0] + Wf[a][1] * n[1] + Wf[a][2] * n[2] + O.X[a][0] * f[0] + O.X[a][1] * f[1] + O.X[a][2] * f[2];
-          v[a] = O.X[0][a] * n[0] + O.X[1][a] * n[1] + O.X[2][a] * n[2] + Vf[a][0] * f[0] + Vf[a][1] * f[1] + Vf[a][2] * f[2];
-        }
-        L.q2(kLdsG + i * 3 + 0) = make_float2(w[0], w[1]);
-        L.q2(kLdsG + i * 3 + 1) = make_float2(w[2], v[0]);
-        L.q2(kLdsG + i * 3 + 2) = make_float2(v[1], v[2]);
+        for (int q = 0; q < 3; ++q) g[q] = Oc[0][q] * ssf2{Kc[0][i], Kc[0][i]};
+#pragma unroll
+        for (int b = 1; b < 6; ++b)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) g[q] = Oc[b][q] * ssf2{Kc[b][i], Kc[b][i]} + g[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L.q2(kLdsG + i * 3 + q) = make_float2(g[q].x, g[q].y);
       }
     }
     static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
