@@ -42,6 +42,11 @@ constexpr float kVcorrMax = 2.0f;
 #endif
 #ifdef SS_PGS_PACKED
 #define SS_PGS_TWIST_ROWS
+// contact operators by packed unit-impulse recursions (two columns per instruction): 0.0914 vs 0.0928 ms/step with
+// the Omega recursion (-DSS_OMEGA_OPERATORS), which is scalar and one dependent chain
+#ifndef SS_OMEGA_OPERATORS
+#define SS_UNIT_COLUMNS_PACKED
+#endif
 #endif
 typedef float ssf2 __attribute__((ext_vector_type(2)));
 
@@ -217,6 +222,94 @@ SSD SV imp_down(const JointCache& jc, const float* ul, const SV& dpar, float* dq
   d.w[ax] += dq;
   if (dq_out) *dq_out = dq;
   return d;
+}
+
+// two columns at once in packed f32: the unloaded down step applies the same joint operator to every column of T, so
+// a pair of columns shares each instruction (v_pk_*), coefficients broadcast
+struct SV2 { ssf2 w[3], v[3]; };
+template <class Model, int J>
+SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
+  constexpr int ax = kAxis[J], k = half_pos(J), ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+  constexpr float rx = Model::r[J][0], ry = Model::r[J][1], rz = Model::r[J][2];
+  const JRec& r = jc.r[k];
+  const float c = r.cs, s = r.sn;
+  SV2 d;
+  d.w[ax] = p.w[ax];
+  d.w[ai] = p.w[ai] * c + p.w[aj] * s;
+  d.w[aj] = p.w[aj] * c - p.w[ai] * s;
+  ssf2 t[3] = {p.v[0], p.v[1], p.v[2]};
+  if constexpr (has_offset<Model, J>()) {         // v_p + w_p x r = v_p - r x w_p
+    if constexpr (ry != 0.f) t[0] -= p.w[2] * ry;
+    if constexpr (rz != 0.f) t[0] += p.w[1] * rz;
+    if constexpr (rz != 0.f) t[1] -= p.w[0] * rz;
+    if constexpr (rx != 0.f) t[1] += p.w[2] * rx;
+    if constexpr (rx != 0.f) t[2] -= p.w[1] * rx;
+    if constexpr (ry != 0.f) t[2] += p.w[0] * ry;
+  }
+  d.v[ax] = t[ax];
+  d.v[ai] = t[ai] * c + t[aj] * s;
+  d.v[aj] = t[aj] * c - t[ai] * s;
+  ssf2 dotv = d.w[0] * r.Uw[0] + d.w[1] * r.Uw[1] + d.w[2] * r.Uw[2] + d.v[0] * r.Uv[0] + d.v[1] * r.Uv[1] + d.v[2] * r.Uv[2];
+  d.w[ax] -= dotv * r.Dinv;
+  return d;
+}
+
+template <class Model, int J>
+SSD SV2 imp_up_pair(const JointCache& jc, ssf2* ul2, const SV2& p) {
+  constexpr int ax = kAxis[J], k = half_pos(J), ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+  constexpr float rx = Model::r[J][0], ry = Model::r[J][1], rz = Model::r[J][2];
+  const JRec& r = jc.r[k];
+  const float c = r.cs, s = r.sn;
+  const ssf2 u = -p.w[ax];
+  ul2[k] = u;
+  const ssf2 du = u * r.Dinv;
+  ssf2 fw[3], fv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { fw[i] = p.w[i] + du * r.Uw[i]; fv[i] = p.v[i] + du * r.Uv[i]; }
+  SV2 o;                                             // f_p = R f_c,  n_p = R n_c + r x f_p
+  o.v[ax] = fv[ax]; o.v[ai] = fv[ai] * c - fv[aj] * s; o.v[aj] = fv[ai] * s + fv[aj] * c;
+  o.w[ax] = fw[ax]; o.w[ai] = fw[ai] * c - fw[aj] * s; o.w[aj] = fw[ai] * s + fw[aj] * c;
+  if constexpr (has_offset<Model, J>()) {
+    if constexpr (ry != 0.f) o.w[0] += o.v[2] * ry;
+    if constexpr (rz != 0.f) o.w[0] -= o.v[1] * rz;
+    if constexpr (rz != 0.f) o.w[1] += o.v[0] * rz;
+    if constexpr (rx != 0.f) o.w[1] -= o.v[2] * rx;
+    if constexpr (rx != 0.f) o.w[2] += o.v[1] * rx;
+    if constexpr (ry != 0.f) o.w[2] -= o.v[0] * ry;
+  }
+  return o;
+}
+template <class Model, int J>
+SSD SV2 imp_down_pair_loaded(const JointCache& jc, const ssf2* ul2, const SV2& p) {
+  constexpr int ax = kAxis[J], k = half_pos(J);
+  const JRec& r = jc.r[k];
+  SV2 d = imp_down_pair<Model, J>(jc, p);            // includes  - Dinv * (U . d)
+  d.w[ax] += ul2[k] * r.Dinv;
+  return d;
+}
+SSD SV2 chol6_solve_neg_pair(const Chol6& L, const SV2& b) {
+  ssf2 y[6] = {-b.w[0], -b.w[1], -b.w[2], -b.v[0], -b.v[1], -b.v[2]};
+  static_for<0, 6>([&](auto Ic) {
+    constexpr int i = decltype(Ic)::value;
+    ssf2 s = y[i];
+    static_for<0, i>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      s -= y[k] * L.template get<i, k>();
+    });
+    y[i] = s * L.di[i];
+  });
+  static_rfor<5, 0>([&](auto Ic) {
+    constexpr int i = decltype(Ic)::value;
+    ssf2 s = y[i];
+    static_for<i + 1, 6>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      s -= y[k] * L.template get<k, i>();
+    });
+    y[i] = s * L.di[i];
+  });
+  SV2 x;
+  x.w[0] = y[0]; x.w[1] = y[1]; x.w[2] = y[2]; x.v[0] = y[3]; x.v[1] = y[4]; x.v[2] = y[5];
+  return x;
 }
 
 // ---- inverse articulated inertia ("Omega") recursion, used for the contact-space operators
@@ -609,23 +702,49 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     // unit-impulse recursions through the tree take ~4.0 k:
     //   T = K = P_7 ... P_3 (columns by the unloaded down pass; LDS), G = Omega_pelvis K^T (LDS),
     //   Lambda_own = Omega_foot (stays in registers: only the row set-up below reads it)
-    auto t_column = [&](int i) {
-      SV d;
+    // T columns, two per pass (columns 2c and 2c+1 share every instruction)
 #pragma unroll
-      for (int m = 0; m < 3; ++m) { d.w[m] = (i == m) ? 1.f : 0.f; d.v[m] = (i == m + 3) ? 1.f : 0.f; }
-      static_for<3, 8>([&](auto Jc) { d = imp_down<Model, decltype(Jc)::value, false>(jc, ul, d, nullptr); });
-      L.q2(kLdsT + i * 3 + 0) = make_float2(d.w[0], d.w[1]);
-      L.q2(kLdsT + i * 3 + 1) = make_float2(d.w[2], d.v[0]);
-      L.q2(kLdsT + i * 3 + 2) = make_float2(d.v[1], d.v[2]);
-    };
-#ifndef SS_T_ILP
-#define SS_T_ILP 6   // all six T columns in one basic block; measured 1 -> 0.1114, 3 -> 0.1113, 6 -> 0.1108 ms/step
-#endif
-#pragma unroll 1
-    for (int i = 0; i < 6 / SS_T_ILP; ++i) {
+    for (int cpair = 0; cpair < 3; ++cpair) {
+      SV2 d;
 #pragma unroll
-      for (int m = 0; m < SS_T_ILP; ++m) t_column(i + m * (6 / SS_T_ILP));
+      for (int m = 0; m < 3; ++m) {
+        d.w[m] = ssf2{2 * cpair == m ? 1.f : 0.f, 2 * cpair + 1 == m ? 1.f : 0.f};
+        d.v[m] = ssf2{2 * cpair == m + 3 ? 1.f : 0.f, 2 * cpair + 1 == m + 3 ? 1.f : 0.f};
+      }
+      static_for<3, 8>([&](auto Jc) { d = imp_down_pair<Model, decltype(Jc)::value>(jc, d); });
+      L.q2(kLdsT + (2 * cpair) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
+      L.q2(kLdsT + (2 * cpair) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
+      L.q2(kLdsT + (2 * cpair) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
+      L.q2(kLdsT + (2 * cpair + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
+      L.q2(kLdsT + (2 * cpair + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
+      L.q2(kLdsT + (2 * cpair + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
     }
+#if defined(SS_UNIT_COLUMNS_PACKED) && defined(SS_PGS_PACKED)
+    // Lambda_own and G by unit impulses on the own foot through the whole tree, two columns per pass in packed f32
+    ssf2 Lc[6][3];                     // column b of Lambda_own as three pairs
+#pragma unroll
+    for (int cpair = 0; cpair < 3; ++cpair) {
+      ssf2 ul2[NH];
+      SV2 p;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        p.w[m] = ssf2{2 * cpair == m ? -1.f : 0.f, 2 * cpair + 1 == m ? -1.f : 0.f};
+        p.v[m] = ssf2{2 * cpair == m + 3 ? -1.f : 0.f, 2 * cpair + 1 == m + 3 ? -1.f : 0.f};
+      }
+      static_rfor<7, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, ul2, p); });
+      SV2 d = chol6_solve_neg_pair(jc.L0, p);
+      static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+      L.q2(kLdsG + (2 * cpair) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
+      L.q2(kLdsG + (2 * cpair) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
+      L.q2(kLdsG + (2 * cpair) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
+      L.q2(kLdsG + (2 * cpair + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
+      L.q2(kLdsG + (2 * cpair + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
+      L.q2(kLdsG + (2 * cpair + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+      static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+      Lc[2 * cpair][0] = ssf2{d.w[0].x, d.w[1].x}; Lc[2 * cpair][1] = ssf2{d.w[2].x, d.v[0].x}; Lc[2 * cpair][2] = ssf2{d.v[1].x, d.v[2].x};
+      Lc[2 * cpair + 1][0] = ssf2{d.w[0].y, d.w[1].y}; Lc[2 * cpair + 1][1] = ssf2{d.w[2].y, d.v[0].y}; Lc[2 * cpair + 1][2] = ssf2{d.v[1].y, d.v[2].y};
+    }
+#else
     OMG O;
     {   // Omega_0 = (L L^T)^-1, column by column
       float inv[6][6];
@@ -675,6 +794,20 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       }
     }
     static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
+#ifdef SS_PGS_PACKED
+    ssf2 Lc[6][3];                     // column b of Lambda_own = [[W, X], [X^T, V]] as three pairs
+    {
+      float LW[3][3], LV[3][3];
+      sym_full(O.W, LW);
+      sym_full(O.V, LV);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        Lc[b][0] = ssf2{LW[0][b], LW[1][b]}; Lc[b][1] = ssf2{LW[2][b], O.X[b][0]}; Lc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
+        Lc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Lc[3 + b][1] = ssf2{O.X[2][b], LV[0][b]}; Lc[3 + b][2] = ssf2{LV[1][b], LV[2][b]};
+      }
+    }
+#endif
+#endif
     SS_PROF(7);
     // own-foot twist under the free velocities
     float V[6];
@@ -694,15 +827,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     ssf2 rYp[12][3], rWp[12][3];
     float rIA[12], rB[4];
     {
-      float LW[3][3], LV[3][3];
-      sym_full(O.W, LW);
-      sym_full(O.V, LV);
-      ssf2 Lc[6][3];                     // column b of Lambda_own = [[W, X], [X^T, V]] as three pairs
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        Lc[b][0] = ssf2{LW[0][b], LW[1][b]}; Lc[b][1] = ssf2{LW[2][b], O.X[b][0]}; Lc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
-        Lc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Lc[3 + b][1] = ssf2{O.X[2][b], LV[0][b]}; Lc[3 + b][2] = ssf2{LV[1][b], LV[2][b]};
-      }
       static_for<0, 4>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
