@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsteppingstone.so")
 SOURCES = ["ss_api.hip"]
-HEADERS = ["ss_math.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "ss_model_tables.hpp",
+HEADERS = ["ss_math.hpp", "ss_pair.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "ss_model_tables.hpp",
            os.path.join("..", "..", "include", "steppingstone.h")]
 # -O3 without the SLP vectorizer, signed zeros not honoured.  Measured on gfx950 / ROCm 7.2:
 #   * SLP vectorisation (packed v_pk_fma_f32 / v_pk_mul_f32) miscompiled the 1-env-per-lane kernel of v1-v3 (wrong,

@@ -20,6 +20,7 @@
 // the 12 joint records, the 12 PGS rows and Lambda_own live in registers (the compiler parks them in AGPRs).
 #pragma once
 #include "ss_math.hpp"
+#include "ss_pair.hpp"
 
 namespace ss {
 
@@ -48,7 +49,6 @@ constexpr float kVcorrMax = 2.0f;
 #define SS_UNIT_COLUMNS_PACKED
 #endif
 #endif
-typedef float ssf2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
 constexpr int kEnvsPerWave = 32;
@@ -226,7 +226,6 @@ SSD SV imp_down(const JointCache& jc, const float* ul, const SV& dpar, float* dq
 
 // two columns at once in packed f32: the unloaded down step applies the same joint operator to every column of T, so
 // a pair of columns shares each instruction (v_pk_*), coefficients broadcast
-struct SV2 { ssf2 w[3], v[3]; };
 template <class Model, int J>
 SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
   constexpr int ax = kAxis[J], k = half_pos(J), ai = (ax + 1) % 3, aj = (ax + 2) % 3;
@@ -425,6 +424,286 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   }
   SS_PROF(1);
 
+#ifndef SS_ABA_SCALAR
+  // ================= leg joints 3..6 and arm joints 13..16 as float pairs {leg, arm} (ss_pair.hpp) =================
+  // Same axes, same massless/massive pattern: one v_pk instruction serves both chains.  Spine joints 0..2 and the
+  // ankle (joint 7) stay scalar.  Topology relied on (asserted): arm on the torso, leg on the pelvis, pelvis on the spine.
+  static_assert(kParent[13] == 0 && kParent[3] == 3 && kParent[2] == 2 && kParent[1] == 1 && kParent[0] == 0 &&
+                kParent[7] == 7 && kParent[6] == 6 && kParent[16] == 16, "half-tree topology");
+  SV a0;
+  {
+    const SV v0 = base_twist(L);
+    ssf2 c2[4], s2[4], qd2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c2[i] = pkv(jc.r[3 + i].cs, jc.r[8 + i].cs); s2[i] = pkv(jc.r[3 + i].sn, jc.r[8 + i].sn);
+      qd2[i] = pkv(qd_all[3 + i], qd_all[8 + i]);
+    }
+    // ---- pass 1: velocities
+    SV vs[3], vfoot;          // bodies 1, 2, 3 and 8
+    SV2 vp[4];                // bodies (4,14) (5,15) (6,16) (7,17)
+    {
+      SV prev = v0;
+      static_for<0, 3>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        SV v = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, prev);
+        v.w[kAxis[j]] += qd_all[j];
+        vs[j] = v;
+        prev = v;
+      });
+      SV2 pp = sv_pack(prev, v0);
+      static_for<0, 4>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        SV2 v = xmotionP<Model, 3 + i, 13 + i>(c2[i], s2[i], pp);
+        v.w[kAxis[3 + i]] += qd2[i];
+        vp[i] = v;
+        pp = v;
+      });
+      vfoot = xmotion<Model, 7>(jc.r[7].cs, jc.r[7].sn, sv_half(pp, 0));
+      vfoot.w[kAxis[7]] += qd_all[7];
+    }
+    SS_PROF(2);
+    // ---- pass 2: articulated inertias, leaves -> root
+#ifdef SS_PAIR_PREFETCH
+    float qs[NH], as_[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) { qs[k] = L.s(S_Q + k); as_[k] = L.s(S_ACT + k); }
+#define SS_QS(k) qs[k]
+#define SS_AS(k) as_[k]
+#else
+#define SS_QS(k) L.s(S_Q + (k))
+#define SS_AS(k) L.s(S_ACT + (k))
+#endif
+    // explicit joint torque and implicit diagonal of joint j (PHYSICS.md 3.1)
+    auto joint_tau = [&](auto Jc, float q, float qd, float act, float& tau, float& Dadd) {
+      constexpr int j = decltype(Jc)::value;
+      constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
+      constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j], tq = Model::torque[j];
+      float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
+      bool lim = viol != 0.f;
+      float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
+      tau = power * tq * act - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
+      Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
+    };
+    // one scalar joint: consumes the articulated inertia / bias of its child body, leaves the joint record, returns the
+    // contribution to the parent (parent coordinates)
+    auto joint_scalar = [&](auto Jc, ABI I, const SV& pA, const SV& vb, ABI& Ip, SV& pp) {
+      constexpr int j = decltype(Jc)::value, k = half_pos(j), ax = kAxis[j];
+      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+      float tau, Dadd;
+      joint_tau(Jc, SS_QS(k), qd_all[k], SS_AS(k), tau, Dadd);
+      const float qd = qd_all[k];
+      JRec& r = jc.r[k];
+      r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
+      r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
+      r.Dinv = SS_RCP(r.Uw[ax] + Dadd);
+      r.u = tau - pA.w[ax];
+      const float* Uw = r.Uw;
+      const float* Uv = r.Uv;
+      float sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
+      float sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
+      I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
+      I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
+      I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
+      I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
+      float cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
+      float cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
+      float du = r.Dinv * r.u;
+      SV pa;
+      {
+        const Sym3 &A = I.A, &C = I.C;
+        float Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
+        float Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
+          pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
+        }
+      }
+      Ip = xinertia<Model, j>(r.cs, r.sn, I);
+      pp = xforce<Model, j>(r.cs, r.sn, pa);
+    };
+    struct JRec2 { ssf2 Uw[3], Uv[3], Dinv, u; };
+    JRec2 jr2[4];
+    auto joint_pair = [&](auto Ic, ABIP I, const SV2& pA, ABIP& Ip, SV2& pp) {
+      constexpr int i = decltype(Ic)::value, jl = 3 + i, ja = 13 + i, kl = 3 + i, ka = 8 + i, ax = kAxis[jl];
+      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+      float taul, Daddl, taua, Dadda;
+      joint_tau(std::integral_constant<int, jl>{}, SS_QS(kl), qd_all[kl], SS_AS(kl), taul, Daddl);
+      joint_tau(std::integral_constant<int, ja>{}, SS_QS(ka), qd_all[ka], SS_AS(ka), taua, Dadda);
+      const ssf2 qd = qd2[i];
+      const SV2& vb = vp[i];
+      JRec2& r = jr2[i];
+      r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
+      r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
+      const ssf2 D = r.Uw[ax] + pkv(Daddl, Dadda);
+      r.Dinv = pkv(SS_RCP(D.x), SS_RCP(D.y));
+      r.u = pkv(taul, taua) - pA.w[ax];
+      const ssf2* Uw = r.Uw;
+      const ssf2* Uv = r.Uv;
+      ssf2 sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
+      ssf2 sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
+      I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
+      I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
+      I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
+      I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
+      ssf2 cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
+      ssf2 cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
+      ssf2 du = r.Dinv * r.u;
+      SV2 pa;
+      {
+        const Sym3P &A = I.A, &C = I.C;
+        ssf2 Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
+        ssf2 Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
+          pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
+        }
+      }
+      Ip = xinertiaP<Model, jl, ja>(c2[i], s2[i], I);
+      pp = xforceP<Model, jl, ja>(c2[i], s2[i], pa);
+      // scalar joint records for the contact stage (sub-register views of the pairs)
+      JRec& rl = jc.r[kl];
+      JRec& ra = jc.r[ka];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { rl.Uw[m] = r.Uw[m].x; ra.Uw[m] = r.Uw[m].y; rl.Uv[m] = r.Uv[m].x; ra.Uv[m] = r.Uv[m].y; }
+      rl.Dinv = r.Dinv.x; ra.Dinv = r.Dinv.y; rl.u = r.u.x; ra.u = r.u.y;
+    };
+    ABI acc0;                  // what reaches the torso: arm (pair of this and the partner lane) + spine
+    SV pacc0;
+    {
+      ABI If;                  // ankle: foot body 8 is a leaf
+      SV pf_;
+      joint_scalar(std::integral_constant<int, 7>{}, abi_body<Model, 8>(), body_bias<Model, 8>(vfoot), vfoot, If, pf_);
+      // knee / elbow (bodies 7, 17): the leg half carries the foot
+      ABIP I2 = abi_zeroP();
+#pragma unroll
+      for (int m = 0; m < 6; ++m) { I2.A.m[m] = pkv(If.A.m[m], 0.f); I2.C.m[m] = pkv(If.C.m[m], 0.f); }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I2.B[a][c] = pkv(If.B[a][c], 0.f);
+      SV2 p2;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { p2.w[m] = pkv(pf_.w[m], 0.f); p2.v[m] = pkv(pf_.v[m], 0.f); }
+      static_rfor<3, 0>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value, bl = 4 + i, ba = 14 + i;     // child bodies of joints 3+i / 13+i
+        if constexpr (massiveP<Model, bl, ba>()) {
+          abi_add_bodyP<Model, bl, ba>(I2);
+          SV2 pb = body_biasP<Model, bl, ba>(vp[i]);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) { p2.w[m] += pb.w[m]; p2.v[m] += pb.v[m]; }
+        }
+        ABIP Ipn;
+        SV2 ppn;
+        joint_pair(Ic, I2, p2, Ipn, ppn);
+        I2 = Ipn;
+        p2 = ppn;
+      });
+      // I2 / p2: leg half in pelvis coordinates, arm half in torso coordinates.  Add the partner lane's limbs
+      // (mirrored), commutative (mine + partner) so that both lanes get bit-identical totals.
+      ABI Il = abi_half(I2, 0), Ia = abi_half(I2, 1);
+      SV pl = sv_half(p2, 0), pa_ = sv_half(p2, 1);
+      {
+        ABI Io = xchg_abi(Il);
+        SV po = xchg_sv(pl);
+        abi_add(Il, Io);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { pl.w[m] += po.w[m]; pl.v[m] += po.v[m]; }
+        Io = xchg_abi(Ia);
+        po = xchg_sv(pa_);
+        abi_add(Ia, Io);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { pa_.w[m] += po.w[m]; pa_.v[m] += po.v[m]; }
+      }
+      // spine: bodies 3 (pelvis, carries both legs), 2, 1
+      ABI Is = Il;
+      SV ps = pl;
+      static_rfor<2, 0>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value, bd = j + 1;
+        if constexpr (Model::mass[bd] != 0.f) {
+          abi_add_body<Model, bd>(Is);
+          SV pb = body_bias<Model, bd>(vs[j]);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) { ps.w[m] += pb.w[m]; ps.v[m] += pb.v[m]; }
+        }
+        ABI Ipn;
+        SV ppn;
+        joint_scalar(Jc, Is, ps, vs[j], Ipn, ppn);
+        Is = Ipn;
+        ps = ppn;
+      });
+      acc0 = Is;
+      abi_add(acc0, Ia);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { pacc0.w[m] = ps.w[m] + pa_.w[m]; pacc0.v[m] = ps.v[m] + pa_.v[m]; }
+    }
+    SS_PROF(3);
+    // ---- base (redundant in both lanes)
+    {
+      ABI I0 = acc0;
+      abi_add_body<Model, 0>(I0);
+      SV pb = body_bias<Model, 0>(v0);
+      SV p0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { p0.w[i] = pacc0.w[i] + pb.w[i]; p0.v[i] = pacc0.v[i] + pb.v[i]; }
+      float M[6][6];
+      abi_dense(I0, M);
+      jc.L0 = chol6(M);
+      a0 = chol6_solve_neg(jc.L0, p0);
+    }
+    SS_PROF(4);
+    // ---- pass 3: accelerations -> free velocities
+    {
+      auto acc_scalar = [&](auto Jc, const SV& aprev, const SV& vb) {
+        constexpr int j = decltype(Jc)::value, k = half_pos(j), ax = kAxis[j];
+        constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+        const JRec& r = jc.r[k];
+        SV a = xmotion<Model, j>(r.cs, r.sn, aprev);
+        float qd = qd_all[k];
+        a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
+        a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
+        float dotv = r.Uw[0] * a.w[0] + r.Uw[1] * a.w[1] + r.Uw[2] * a.w[2] + r.Uv[0] * a.v[0] + r.Uv[1] * a.v[1] +
+                     r.Uv[2] * a.v[2];
+        float qdd = r.Dinv * (r.u - dotv);
+        a.w[ax] += qdd;
+        SS_QDF(k) = qd + h * qdd;
+        return a;
+      };
+      SV prev = a0;
+      static_for<0, 3>([&](auto Jc) { prev = acc_scalar(Jc, prev, vs[decltype(Jc)::value]); });
+      SV2 pp = sv_pack(prev, a0);
+      static_for<0, 4>([&](auto Ic) {
+        constexpr int i = decltype(Ic)::value, jl = 3 + i, ja = 13 + i, ax = kAxis[jl];
+        constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+        const JRec2& r = jr2[i];
+        const SV2& vb = vp[i];
+        SV2 a = xmotionP<Model, jl, ja>(c2[i], s2[i], pp);
+        const ssf2 qd = qd2[i];
+        a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
+        a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
+        ssf2 dotv = r.Uw[0] * a.w[0] + r.Uw[1] * a.w[1] + r.Uw[2] * a.w[2] + r.Uv[0] * a.v[0] + r.Uv[1] * a.v[1] +
+                    r.Uv[2] * a.v[2];
+        ssf2 qdd = r.Dinv * (r.u - dotv);
+        a.w[ax] += qdd;
+        const ssf2 qf = qd + qdd * h;
+        SS_QDF(3 + i) = qf.x;
+        SS_QDF(8 + i) = qf.y;
+        pp = a;
+      });
+      acc_scalar(std::integral_constant<int, 7>{}, sv_half(pp, 0), vfoot);
+    }
+  }
+#else   // SS_ABA_SCALAR: every joint on its own (leg and arm chains interleaved at source level)
   // ---- pass 1: velocities (kept in LDS; each chain's predecessor stays in registers)
   {
     const SV v0 = base_twist(L);
@@ -593,6 +872,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       SS_QDF(k) = qd + h * qdd;
     });
   }
+#endif  // SS_ABA_SCALAR
   float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
   float Rb[3][3];
   quat_rot(quat, Rb);
