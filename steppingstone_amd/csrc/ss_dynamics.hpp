@@ -405,7 +405,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #define SS_VEL_PUT(b, v) vel_put<b>(L, v)
 #define SS_VEL_GET(b) vel_get<b>(L)
 #endif
-#ifdef SS_QDF_REGS
+#ifndef SS_QDF_LDS       // free joint velocities in registers: 0.0871 vs 0.0890 ms/step through LDS
   float qdfr[NH];
 #define SS_QDF(k) qdfr[k]
 #else
