@@ -301,7 +301,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   // Only what the substeps need is loaded before them; everything the step's epilogue needs (stone tilts,
   // counters, episode statistics) is (re)loaded afterwards from the L2-hot arrays, so that nothing sits in scratch
   // across the four substeps (those parked values were 2.2 MB of scratch write-back per launch).
-  {
+  {   // measured: merging these loads with the state loads below is slower (0.0867 vs 0.0857 ms/step)
     Cache c0;
     load_cache(P, e, c0);
 #pragma unroll
@@ -311,31 +311,46 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     }
   }
 
-  // 1. this lane's half of the state, mirrored for the left lane, straight into LDS
-  L.s(S_POS + 0) = F[(F_POS + 0) * np]; L.s(S_POS + 1) = m * F[(F_POS + 1) * np]; L.s(S_POS + 2) = F[(F_POS + 2) * np];
-  L.s(S_QUAT + 0) = F[(F_QUAT + 0) * np]; L.s(S_QUAT + 1) = m * F[(F_QUAT + 1) * np];
-  L.s(S_QUAT + 2) = F[(F_QUAT + 2) * np]; L.s(S_QUAT + 3) = m * F[(F_QUAT + 3) * np];
-  L.s(S_VW + 0) = m * F[(F_VEL + 0) * np]; L.s(S_VW + 1) = F[(F_VEL + 1) * np]; L.s(S_VW + 2) = m * F[(F_VEL + 2) * np];
-  L.s(S_VV + 0) = F[(F_VEL + 3) * np]; L.s(S_VV + 1) = m * F[(F_VEL + 4) * np]; L.s(S_VV + 2) = F[(F_VEL + 5) * np];
+  // 1. this lane's half of the state, mirrored for the left lane, into LDS.  All global loads are issued before the
+  //    first LDS store: written load-store-load-store the compiler waited for every load in turn (~25 exposed L2
+  //    round trips per step).
+  float gin[13], qin[NH], qdin[NH], ain[NH];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gin[i] = F[(F_POS + i) * np];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gin[3 + i] = F[(F_QUAT + i) * np];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gin[7 + i] = F[(F_VEL + i) * np];
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);         // the left twin of a right-side joint
+    const int gj = side ? jl : jr;
+    qin[k] = F[(F_Q + gj) * np];
+    qdin[k] = F[(F_QD + gj) * np];
+    if constexpr (!RANDOM_ACT) ain[k] = io.act[(size_t)e * NJ + gj];
+  });
   uint32_t ra[6][4];
   if constexpr (RANDOM_ACT) {
 #pragma unroll
     for (int b = 0; b < 6; ++b)
       philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
   }
+  L.s(S_POS + 0) = gin[0]; L.s(S_POS + 1) = m * gin[1]; L.s(S_POS + 2) = gin[2];
+  L.s(S_QUAT + 0) = gin[3]; L.s(S_QUAT + 1) = m * gin[4]; L.s(S_QUAT + 2) = gin[5]; L.s(S_QUAT + 3) = m * gin[6];
+  L.s(S_VW + 0) = m * gin[7]; L.s(S_VW + 1) = gin[8]; L.s(S_VW + 2) = m * gin[9];
+  L.s(S_VV + 0) = gin[10]; L.s(S_VV + 1) = m * gin[11]; L.s(S_VV + 2) = gin[12];
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
-    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);         // the left twin of a right-side joint
-    const int gj = side ? jl : jr;
+    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
     const float sg = mirror_flips(jr) ? m : 1.f;
-    L.s(S_Q + k) = sg * F[(F_Q + gj) * np];
-    L.s(S_QD + k) = sg * F[(F_QD + gj) * np];
+    L.s(S_Q + k) = sg * qin[k];
+    L.s(S_QD + k) = sg * qdin[k];
     float a;
     if constexpr (RANDOM_ACT) {
       const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
       a = 2.f * u01(bits) - 1.f;
     } else {
-      const float x = io.act[(size_t)e * NJ + gj];
+      const float x = ain[k];
       a = fminf(fmaxf(x, -1.f), 1.f);
       a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
     }
