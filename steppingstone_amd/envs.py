@@ -178,6 +178,14 @@ class SteppingStoneVecEnv:
         self._info = torch.zeros((n, 5), dtype=torch.int32, device=dev)
         self._act = torch.zeros((n, ACT_DIM), dtype=torch.float32, device=dev)
         self._pending = False
+        # numpy drop-in mode on a GPU: pinned staging buffers, one H->D copy of the actions and one D->H copy of the
+        # packed [N,62] = obs | rew | done block per step (instead of four pageable copies)
+        self._pinned = None
+        if self.return_numpy and torch.device(dev).type == "cuda":
+            self._pinned = {"act": torch.zeros((n, ACT_DIM), dtype=torch.float32).pin_memory(),
+                            "out": torch.zeros((n, OBS_DIM + 2), dtype=torch.float32).pin_memory(),
+                            "dev": torch.zeros((n, OBS_DIM + 2), dtype=torch.float32, device=dev),
+                            "event": torch.cuda.Event()}
         self._tstart = time.time()
         self.yaw_samples = np.linspace(-20.0, 20.0, GRID) * DEG
         self.pitch_samples = np.linspace(-30.0, 30.0, GRID) * DEG
@@ -195,6 +203,17 @@ class SteppingStoneVecEnv:
         return self._out_obs()
 
     def step_async(self, actions):
+        if self._pinned is not None and not torch.is_tensor(actions):
+            pb = self._pinned
+            a = np.asarray(actions, dtype=np.float32)
+            assert a.shape[0] == self.num_envs, "expected %d actions, got %d" % (self.num_envs, a.shape[0])
+            pb["act"].numpy()[...] = a.reshape(self.num_envs, ACT_DIM)
+            self._act.copy_(pb["act"], non_blocking=True)
+            self.backend.step_packed(self._act, False, 0, pb["dev"], self._info)
+            pb["out"].copy_(pb["dev"], non_blocking=True)
+            pb["event"].record()
+            self._pending = "pinned"
+            return
         if torch.is_tensor(actions):
             a = actions.to(device=self.device, dtype=torch.float32)
         else:
@@ -205,6 +224,15 @@ class SteppingStoneVecEnv:
         self._pending = True
 
     def step_wait(self):
+        if self._pending == "pinned":
+            self._pending = False
+            pb = self._pinned
+            pb["event"].synchronize()
+            out = pb["out"].numpy()
+            obs = out[:, :OBS_DIM].copy()                       # fresh arrays every step, like common/envs_utils.py:619
+            rew = out[:, OBS_DIM].astype(np.float64)
+            done = out[:, OBS_DIM + 1] > 0.5
+            return obs, rew, done, self._info_dicts(done)
         self._pending = False
         if not self.return_numpy:
             return self._obs, self._rew, self._done.bool(), self._info_tensors()

@@ -482,3 +482,27 @@ def test_gpu_rounding_error_is_comparable_to_the_fp32_cpu_path():
     assert med_g < 4 * med_32 + 1e-7 and p95_g < 4 * p95_32 + 1e-6
     assert med_g < 1e-4          # the north-star's per-step bound, against fp64 of OUR specification (PyBullet is absent)
     g.close()
+
+
+def test_numpy_mode_pinned_path_equals_tensor_mode():
+    """The reference-style caller (numpy in / numpy out + info dicts) goes through pinned staging and the packed block;
+    it must return exactly what the tensor mode returns, fresh arrays every step."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    n = 300
+    a_env = gpu_env("MikeStepperEnv-v0", n, seed=5)
+    b_env = SteppingStoneVecEnv("MikeStepperEnv-v0", n, seed=5, device="cuda:0", return_numpy=False)
+    assert a_env._pinned is not None
+    assert np.array_equal(a_env.reset(), b_env.reset().cpu().numpy())
+    prev = None
+    for t in range(40):
+        act = b_env.random_actions(t)
+        o1, r1, d1, infos = a_env.step(act.cpu().numpy())
+        o2, r2, d2, it = b_env.step(act)
+        assert o1.dtype == np.float32 and r1.dtype == np.float64 and d1.dtype == np.bool_ and len(infos) == n
+        assert np.array_equal(o1, o2.cpu().numpy()) and np.array_equal(r1, r2.cpu().numpy().astype(np.float64))
+        assert np.array_equal(d1, d2.cpu().numpy())
+        for i in np.nonzero(d1)[0]:
+            assert abs(infos[i]["episode"]["r"] - float(it["ep_ret"][i])) < 1e-5 and infos[i]["episode"]["l"] == int(it["ep_len"][i])
+        assert prev is None or prev is not o1
+        prev = o1
+    a_env.close(); b_env.close()
