@@ -28,6 +28,7 @@ ENV_ID = "Walker3DStepperEnv-v0"
 # obs 240 B, rew 4 B, done 1 B, info 20 B = 521 B.  (Actions are generated on the device: 0 B.)
 ALGO_BYTES_PER_ENV_STEP = 348 + 521
 HBM_PEAK_GBS = 8000.0
+VALU_FP32_PEAK_TFLOPS = 157.3          # packed-f32 vector peak (MI355X_MICROARCH.md): 256 CUs x 2.4 GHz x 256 flop/clk
 
 
 def recorded_traffic(n_envs):
@@ -40,6 +41,18 @@ def recorded_traffic(n_envs):
         return None, None
     with open(files[-1]) as f:
         return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
+def recorded_flops_per_env_step():
+    """fp32 VALU flops per env-step from the committed SQ-counter profile (SQ_INSTS_VALU_FLOPS_FP32 counts flops per
+    wavefront-instruction lane; one wavefront = 64 lanes = 32 envs); null if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_4096.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        v = json.load(f)["per_wave_per_launch"].get("SQ_INSTS_VALU_FLOPS_FP32")
+    return (float(v) * 64.0 / 32.0 if v else None), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(seconds_budget=15.0):
@@ -153,6 +166,12 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
                          "note": "VALU-issue-bound per-lane rigid-body dynamics (80 % VALU-busy, one wavefront per SIMD), not HBM-bound (DESIGN.md 4.1)"},
         }
+        flop, flop_src = recorded_flops_per_env_step()
+        if flop:
+            tf = flop * n_local / (kernel_ms * 1e-3) / 1e12
+            out["roofline"]["valu_fp32"] = {"flop_per_env_step": flop, "source": flop_src, "achieved": tf, "peak": VALU_FP32_PEAK_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": tf / VALU_FP32_PEAK_TFLOPS,
+                                            "note": "secondary roofline: packed-f32 vector peak of the chip; 4096 envs occupy 128 of its 1024 SIMDs"}
         if world == 1 and not use_dist and n_local < 32768:
             # not the metric: the same kernel with every SIMD of the chip occupied (4 wavefronts per CU)
             big = SteppingStoneVecEnv(args.env, 32768, seed=0, device=dev, return_numpy=False)
@@ -165,6 +184,7 @@ def main():
             bms = b0.elapsed_time(b1) / 200
             out["capacity"] = {"envs_per_gpu": 32768, "ms_per_step": bms, "value": 32768 / (bms * 1e-3), "unit": "env-steps/s",
                                "roofline_frac": ALGO_BYTES_PER_ENV_STEP * 32768 / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "valu_fp32_frac": (flop * 32768 / (bms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS) if flop else None,
                                "note": "same kernel at 32768 envs on this GPU (all 1024 SIMDs occupied); not the BASELINE config"}
             big.close()
         if world == 1 and not args.no_cpu_baseline:
