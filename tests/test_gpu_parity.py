@@ -506,3 +506,38 @@ def test_numpy_mode_pinned_path_equals_tensor_mode():
         assert prev is None or prev is not o1
         prev = o1
     a_env.close(); b_env.close()
+
+
+def test_remaining_hooks_match_oracle():
+    """update_specialist (ring window of the sampler), set_robot_params(power), auto-reset off (plain gym semantics of
+    make_env callers): same decisions and numbers as the oracle."""
+    n = 128
+    g = gpu_env("Walker3DStepperEnv-v0", n, seed=41)
+    o = ol.OracleEnv("walker3d", n, seed=41)
+    g.update_specialist(3); o.set_specialist(3)
+    g.set_robot_params({"power": 0.5}); o.set_power(0.5)
+    assert np.abs(g.reset() - o.reset()).max() < 1e-6
+    for t in range(12):
+        st = o.get_state()
+        g.set_state(st)
+        a = o.random_actions(t)
+        oo, ro, do, io = o.step(a)
+        og, rg, dg, ig = g.step(a)
+        ok = np.abs(og - oo).max(axis=1) < 2e-3
+        assert ok.mean() > 0.99 and np.array_equal(dg[ok], do[ok].astype(bool))
+    # specialist ring: stones drawn while standing on the target come from cells at Chebyshev distance 3 only
+    g.set_state(_stand_on_target(o, n))
+    zero = np.zeros((n, 21), np.float32)
+    for t in range(3):
+        o.step(zero); g.step(zero)
+        sg, so = g.get_state().cpu().numpy(), o.get_state()
+        assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS]) and np.abs(sg[:, 65:] - so[:, 65:]).max() < 1e-5
+        g.set_state(so)
+    # auto-reset off: a finished env reports done and keeps its terminal observation until reset() is called
+    g.backend.set_auto_reset(False); o.set_auto_reset(0)
+    st = o.get_state(); st[:8, 2] -= 3.0         # drop eight robots far below the fall threshold
+    o.set_state(st); g.set_state(st)
+    oo, ro, do, io = o.step(zero)
+    og, rg, dg, ig = g.step(zero)
+    assert dg[:8].all() and np.array_equal(dg, do.astype(bool)) and np.abs(og - oo).max() < 2e-3
+    g.close()
