@@ -162,7 +162,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
-                         "kernel": "ss::step_kernel<ModelWalker3D,true>", "kernel_ms": kernel_ms,
+                         "kernel": "ss::step_kernel_helped<ModelWalker3D,true,3> (ss::step_kernel above 16384 envs)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
                          "note": "VALU-issue-bound per-lane rigid-body dynamics (80 % VALU-busy, one wavefront per SIMD), not HBM-bound (DESIGN.md 4.1)"},
         }

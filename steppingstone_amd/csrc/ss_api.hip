@@ -35,6 +35,8 @@ struct ss_env {
   float* prob_shared;   // [121]
   float* prob_env;      // [121][npad] or null
   float* obs_rows;      // [n][60] scratch: current observation rows for create_temp_states
+  int helpers;          // -1 auto, else 0 / 1 / 3 helper wavefronts (env SS_HELPERS)
+  int helper_max_groups;  // auto: use the helper wavefront up to this many 32-env groups
 };
 
 namespace {
@@ -68,12 +70,28 @@ inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
 
 template <bool RANDOM>
 int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
-  const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane workgroup
+  const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane wavefront
   SS_HIP(hipSetDevice(env->device));                   // the stream belongs to this device
-  if (env->kind == SS_WALKER3D)
-    hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
-  else
-    hipLaunchKernelGGL((ss::step_kernel<ss::ModelMike, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
+  // helper wavefronts (contact operators on a second SIMD) while the batch leaves SIMDs idle
+  // (three while every 4-wavefront workgroup gets a CU to itself, one while two 2-wavefront workgroups fit a CU)
+  const int helpers = env->helpers >= 0 ? env->helpers
+                      : ((int)grid.x <= env->helper_max_groups / 2 ? 3 : ((int)grid.x <= env->helper_max_groups ? 1 : 0));
+  if (helpers == 3) {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::step_kernel_helped<ss::ModelWalker3D, RANDOM, 3>), grid, dim3(4 * ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::step_kernel_helped<ss::ModelMike, RANDOM, 3>), grid, dim3(4 * ss::kWave), 0, st, env->P, io);
+  } else if (helpers > 0) {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::step_kernel_helped<ss::ModelWalker3D, RANDOM, 1>), grid, dim3(2 * ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::step_kernel_helped<ss::ModelMike, RANDOM, 1>), grid, dim3(2 * ss::kWave), 0, st, env->P, io);
+  } else {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::step_kernel<ss::ModelWalker3D, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::step_kernel<ss::ModelMike, RANDOM>), grid, dim3(ss::kWave), 0, st, env->P, io);
+  }
   SS_HIP(hipGetLastError());
   return SS_OK;
 }
@@ -100,6 +118,13 @@ int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t see
   std::memset(env, 0, sizeof *env);
   env->kind = kind;
   env->device = device;
+  {   // SS_HELPERS=0|1|3 forces the number of helper wavefronts; default: as many as cannot cost throughput
+    const char* h = std::getenv("SS_HELPERS");
+    env->helpers = h ? std::atoi(h) : -1;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    env->helper_max_groups = 2 * cus;     // two 2-wavefront workgroups per CU = its four SIMDs
+  }
   ss::Params& P = env->P;
   P.n = num_envs;
   P.npad = (num_envs + ss::kWave - 1) / ss::kWave * ss::kWave;

@@ -57,6 +57,11 @@ constexpr int kSlotsA = 20;            // region A: ABA-phase body twists (78 sc
 constexpr int kLdsG = 0;               // 6 columns x 3 float2: pelvis twist per unit impulse on the own foot
 constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist per unit pelvis twist
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
+// helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
+// of the spine+leg chain (8 x 9 floats), the base Cholesky factor (21), and back: the six Lambda_own columns (36)
+constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandFloats = 129;
+constexpr int kHandSlots = (kHandFloats + 3) / 4;  // float4-slots per lane
+constexpr int kHandBase = kLdsSlots * kWave * 4;   // in floats
 constexpr int NH = 12;                 // joints per half
 enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_QDF = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
        S_END = 79 };
@@ -96,6 +101,7 @@ struct Lds {       // lane-private view of the workgroup's LDS
   int lane;
   SSD float2& q2(int item) const { return reinterpret_cast<float2*>(base)[item * kWave + lane]; }   // region A, 8-B items
   SSD float& s(int idx) const { return base[kScalarBase + idx * kWave + lane]; }   // region B scalar
+  SSD float& hs(int idx) const { return base[kHandBase + idx * kWave + lane]; }    // hand-off scalar (helper variant)
   SSD float& av(int idx) const { return base[idx * kWave + lane]; }                // ABA-phase scalar over region A
 };
 
@@ -388,9 +394,104 @@ SSD OMG omega_step(const JRec& r, const OMG& O) {
   return o;
 }
 
+// Contact-space operators for the column pair (2c, 2c+1): T = K = P_7 ... P_3 (own-foot twist per unit pelvis twist through
+// the unloaded leg; LDS), and by unit impulses on the own foot through the whole tree G (pelvis twist; LDS) and
+// Lambda_own (own-foot twist; returned as columns of three pairs).  Two columns share every instruction (packed f32).
+// Opaque register copies of what the packed recursions read as scalars: the callee is optimised on its own before it
+// is inlined, and instcombine then widens 'splat (load float)' of neighbouring record fields into overlapping
+// <2 x float> loads, which pins the record in scratch after inlining.
+SSD JRec opaque_rec(const JRec& r) {
+  JRec o = r;
+  SS_REG(o.cs); SS_REG(o.sn); SS_REG(o.Dinv); SS_REG(o.u);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) { SS_REG(o.Uw[m]); SS_REG(o.Uv[m]); }
+  return o;
+}
+struct LamPair { ssf2 a[3], b[3]; };
+template <class Model, int CPAIR>
+SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
+  JointCache jc;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { jc.L0.l[i] = jc_in.L0.l[i]; SS_REG(jc.L0.l[i]); }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { jc.L0.di[i] = jc_in.L0.di[i]; SS_REG(jc.L0.di[i]); }
+  {
+    SV2 d;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      d.w[m] = ssf2{2 * CPAIR == m ? 1.f : 0.f, 2 * CPAIR + 1 == m ? 1.f : 0.f};
+      d.v[m] = ssf2{2 * CPAIR == m + 3 ? 1.f : 0.f, 2 * CPAIR + 1 == m + 3 ? 1.f : 0.f};
+    }
+    static_for<3, 8>([&](auto Jc) { d = imp_down_pair<Model, decltype(Jc)::value>(jc, d); });
+    L.q2(kLdsT + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
+    L.q2(kLdsT + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
+    L.q2(kLdsT + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
+    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
+    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
+    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+  }
+  ssf2 ul2[NH];
+  SV2 p;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    p.w[m] = ssf2{2 * CPAIR == m ? -1.f : 0.f, 2 * CPAIR + 1 == m ? -1.f : 0.f};
+    p.v[m] = ssf2{2 * CPAIR == m + 3 ? -1.f : 0.f, 2 * CPAIR + 1 == m + 3 ? -1.f : 0.f};
+  }
+  static_rfor<7, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, ul2, p); });
+  SV2 d = chol6_solve_neg_pair(jc.L0, p);
+  static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+  L.q2(kLdsG + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
+  L.q2(kLdsG + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
+  L.q2(kLdsG + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
+  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
+  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
+  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+  static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+  LamPair o;
+  o.a[0] = ssf2{d.w[0].x, d.w[1].x}; o.a[1] = ssf2{d.w[2].x, d.v[0].x}; o.a[2] = ssf2{d.v[1].x, d.v[2].x};
+  o.b[0] = ssf2{d.w[0].y, d.w[1].y}; o.b[1] = ssf2{d.w[2].y, d.v[0].y}; o.b[2] = ssf2{d.v[1].y, d.v[2].y};
+  return o;
+}
+
+#ifndef SS_HOST_HARNESS
+// Helper wavefront of the small-batch variant: between the two workgroup barriers of a substep it computes the
+// contact operators of its column pairs from the joint records the main wavefront handed over, while the main
+// wavefront runs pass 3, forward kinematics and contact detection.
+template <class Model, int HELPERS>
+__device__ __forceinline__ void helper_substep(int helper, const Lds& L) {
+  __syncthreads();                                   // #1: joint records are in the hand-off region
+  JointCache jc;
+  static_for<0, 8>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    JRec& r = jc.r[k];
+    r.cs = L.hs(kHandJc + k * 9 + 0); r.sn = L.hs(kHandJc + k * 9 + 1); r.Dinv = L.hs(kHandJc + k * 9 + 2);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { r.Uw[m] = L.hs(kHandJc + k * 9 + 3 + m); r.Uv[m] = L.hs(kHandJc + k * 9 + 6 + m); }
+  });
+#pragma unroll
+  for (int i = 0; i < 15; ++i) jc.L0.l[i] = L.hs(kHandL0 + i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) jc.L0.di[i] = L.hs(kHandL0 + 15 + i);
+  static_for<0, 3>([&](auto Cc) {
+    constexpr int c = decltype(Cc)::value;
+    if (HELPERS == 1 || helper == c) {
+      const LamPair lp = operator_pair<Model, c>(jc, L);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        L.hs(kHandLc + (2 * c) * 6 + 2 * i) = lp.a[i].x; L.hs(kHandLc + (2 * c) * 6 + 2 * i + 1) = lp.a[i].y;
+        L.hs(kHandLc + (2 * c + 1) * 6 + 2 * i) = lp.b[i].x; L.hs(kHandLc + (2 * c + 1) * 6 + 2 * i + 1) = lp.b[i].y;
+      }
+    }
+  });
+  __syncthreads();                                   // #2: G, T and Lambda_own are ready
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // State (q, qd, base pose/twist), stones and clipped actions of THIS lane's world live in LDS (region B).
-template <class Model>
+template <class Model, int HELPERS = 0>
 SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
@@ -676,6 +777,22 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       a0 = chol6_solve_neg(jc.L0, p0);
     }
     SS_PROF(4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (HELPERS > 0) {       // hand the spine+leg joint records and the base factor to the helper wavefront(s)
+      static_for<0, 8>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        const JRec& r = jc.r[k];
+        L.hs(kHandJc + k * 9 + 0) = r.cs; L.hs(kHandJc + k * 9 + 1) = r.sn; L.hs(kHandJc + k * 9 + 2) = r.Dinv;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { L.hs(kHandJc + k * 9 + 3 + m) = r.Uw[m]; L.hs(kHandJc + k * 9 + 6 + m) = r.Uv[m]; }
+      });
+#pragma unroll
+      for (int m = 0; m < 15; ++m) L.hs(kHandL0 + m) = jc.L0.l[m];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) L.hs(kHandL0 + 15 + m) = jc.L0.di[m];
+      __syncthreads();                 // #1
+    }
+#endif
     // ---- pass 3: accelerations -> free velocities
     {
       auto acc_scalar = [&](auto Jc, const SV& aprev, const SV& vb) {
@@ -985,6 +1102,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   for (int k = 0; k < NH; ++k) dqd[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dv0.w[i] = 0.f; dv0.v[i] = 0.f; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (HELPERS > 0) __syncthreads();   // #2: the helper wavefront(s) have written G, T and Lambda_own
+#endif
 #ifdef SS_ABLATE_CONTACT
   if (false) {
 #else
@@ -996,6 +1116,22 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     // unit-impulse recursions through the tree take ~4.0 k:
     //   T = K = P_7 ... P_3 (columns by the unloaded down pass; LDS), G = Omega_pelvis K^T (LDS),
     //   Lambda_own = Omega_foot (stays in registers: only the row set-up below reads it)
+#if defined(SS_UNIT_COLUMNS_PACKED) && defined(SS_PGS_PACKED)
+    ssf2 Lc[6][3];                     // column b of Lambda_own as three pairs
+    if constexpr (HELPERS > 0) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Lc[b][i] = pkv(L.hs(kHandLc + b * 6 + 2 * i), L.hs(kHandLc + b * 6 + 2 * i + 1));
+    } else {
+      static_for<0, 3>([&](auto Cc) {
+        constexpr int c = decltype(Cc)::value;
+        const LamPair lp = operator_pair<Model, c>(jc, L);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Lc[2 * c][i] = lp.a[i]; Lc[2 * c + 1][i] = lp.b[i]; }
+      });
+    }
+#else
     // T columns, two per pass (columns 2c and 2c+1 share every instruction)
 #pragma unroll
     for (int cpair = 0; cpair < 3; ++cpair) {
@@ -1013,32 +1149,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       L.q2(kLdsT + (2 * cpair + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
       L.q2(kLdsT + (2 * cpair + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
     }
-#if defined(SS_UNIT_COLUMNS_PACKED) && defined(SS_PGS_PACKED)
-    // Lambda_own and G by unit impulses on the own foot through the whole tree, two columns per pass in packed f32
-    ssf2 Lc[6][3];                     // column b of Lambda_own as three pairs
-#pragma unroll
-    for (int cpair = 0; cpair < 3; ++cpair) {
-      ssf2 ul2[NH];
-      SV2 p;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        p.w[m] = ssf2{2 * cpair == m ? -1.f : 0.f, 2 * cpair + 1 == m ? -1.f : 0.f};
-        p.v[m] = ssf2{2 * cpair == m + 3 ? -1.f : 0.f, 2 * cpair + 1 == m + 3 ? -1.f : 0.f};
-      }
-      static_rfor<7, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, ul2, p); });
-      SV2 d = chol6_solve_neg_pair(jc.L0, p);
-      static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
-      L.q2(kLdsG + (2 * cpair) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
-      L.q2(kLdsG + (2 * cpair) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
-      L.q2(kLdsG + (2 * cpair) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
-      L.q2(kLdsG + (2 * cpair + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
-      L.q2(kLdsG + (2 * cpair + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
-      L.q2(kLdsG + (2 * cpair + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
-      static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
-      Lc[2 * cpair][0] = ssf2{d.w[0].x, d.w[1].x}; Lc[2 * cpair][1] = ssf2{d.w[2].x, d.v[0].x}; Lc[2 * cpair][2] = ssf2{d.v[1].x, d.v[2].x};
-      Lc[2 * cpair + 1][0] = ssf2{d.w[0].y, d.w[1].y}; Lc[2 * cpair + 1][1] = ssf2{d.w[2].y, d.v[0].y}; Lc[2 * cpair + 1][2] = ssf2{d.v[1].y, d.v[2].y};
-    }
-#else
     OMG O;
     {   // Omega_0 = (L L^T)^-1, column by column
       float inv[6][6];

@@ -9,6 +9,9 @@
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
 #pragma once
 #include "ss_dynamics.hpp"
+#ifndef SS_NUM_SUBSTEPS
+#define SS_NUM_SUBSTEPS 4
+#endif
 #include "../../include/steppingstone.h"
 
 namespace ss {
@@ -288,7 +291,7 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
 
 // One control step, lane `lane_global` = 2*env + side (side 0: right half, true world; side 1: left half, mirrored
 // world).  PHYSICS.md section 4.  Env-level logic runs redundantly (and identically) in both lanes in the true world.
-template <class Model, bool RANDOM_ACT>
+template <class Model, bool RANDOM_ACT, int HELPERS = 0>
 SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, float* lds) {
   const int e_raw = lane_global >> 1, side = lane_global & 1;
   const bool valid = e_raw < P.n;
@@ -366,10 +369,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   prof.last = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
-#ifndef SS_NUM_SUBSTEPS
-#define SS_NUM_SUBSTEPS 4
-#endif
-  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model>(SS_PROF_ARG P.power, fr, L);
+  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG P.power, fr, L);
   SS_PROF(12);
   SS_MEMBAR();
   SS_OPAQUE(e);                                 // recompute every global address below instead of spilling 27 pointers
@@ -650,6 +650,22 @@ template <class Model, bool RANDOM_ACT>
 __global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
   __shared__ float4 lds4[kLdsSlots * kWave];
   step_env<Model, RANDOM_ACT>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, reinterpret_cast<float*>(lds4));   // lane = 2*env + side
+}
+// Small-batch variant: 1 + HELPERS wavefronts per 32 envs.  Wavefront 0 runs the step as above; the helper wavefront(s)
+// compute the contact-space operators of every substep concurrently on the CU's other SIMDs (ss_dynamics.hpp:
+// helper_substep).  Worth it only while the batch leaves SIMDs idle (4096 envs occupy 128 of 1024).
+template <class Model, bool RANDOM_ACT, int HELPERS>
+__global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(Params P, StepIO io) {
+  __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
+  float* lds = reinterpret_cast<float*>(lds4);
+  if (wave == 0) {
+    step_env<Model, RANDOM_ACT, HELPERS>(P, io, blockIdx.x * kWave + lane, lane, lds);
+  } else {
+    const Lds L{lds, lane};
+#pragma unroll 1
+    for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L);
+  }
 }
 #endif  // SS_HOST_HARNESS
 

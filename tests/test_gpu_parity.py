@@ -541,3 +541,28 @@ def test_remaining_hooks_match_oracle():
     og, rg, dg, ig = g.step(zero)
     assert dg[:8].all() and np.array_equal(dg, do.astype(bool)) and np.abs(og - oo).max() < 2e-3
     g.close()
+
+
+def test_kernel_variants_are_bitwise_identical():
+    """The plain step kernel and the helper-wavefront variants (1 or 3 extra wavefronts computing the contact operators;
+    chosen by batch size) must produce the same bits: results may not depend on batch size or GPU count."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    outs = []
+    old = os.environ.get("SS_HELPERS")
+    try:
+        for h in ("0", "1", "3"):
+            os.environ["SS_HELPERS"] = h
+            e = SteppingStoneVecEnv("MikeStepperEnv-v0", 1000, seed=21, device="cuda:0", return_numpy=False)
+            e.update_curriculum(5)
+            e.reset()
+            for t in range(40):
+                o, r, d = e.rollout_random(1, t0=t)
+            outs.append((o.clone(), r.clone(), d.clone(), e.get_state().clone()))
+            e.close()
+    finally:
+        if old is None:
+            os.environ.pop("SS_HELPERS", None)
+        else:
+            os.environ["SS_HELPERS"] = old
+    for k in (1, 2):
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[k])), "variant %d differs" % k
