@@ -45,14 +45,18 @@ def recorded_traffic(n_envs):
 
 def recorded_flops_per_env_step():
     """fp32 VALU flops per env-step from the committed SQ-counter profile (SQ_INSTS_VALU_FLOPS_FP32 counts flops per
-    wavefront-instruction lane; one wavefront = 64 lanes = 32 envs); null if absent."""
+    wavefront-instruction lane); null if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_4096.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
-        v = json.load(f)["per_wave_per_launch"].get("SQ_INSTS_VALU_FLOPS_FP32")
-    return (float(v) * 64.0 / 32.0 if v else None), os.path.relpath(files[-1], ROOT)
+        d = json.load(f)
+    v = d["per_wave_per_launch"].get("SQ_INSTS_VALU_FLOPS_FP32")
+    if not v:
+        return None, None
+    # per-wavefront mean x wavefronts per launch (main + helper wavefronts) x 64 lanes, per env of the launch
+    return float(v) * float(d["waves_per_launch"]) * 64.0 / float(d["envs"]), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(seconds_budget=15.0):
