@@ -576,13 +576,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     }
     SS_PROF(2);
     // ---- pass 2: articulated inertias, leaves -> root
-#ifdef SS_PAIR_PREFETCH
-    float qs[NH], as_[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) { qs[k] = L.s(S_Q + k); as_[k] = L.s(S_ACT + k); }
-#define SS_QS(k) qs[k]
-#define SS_AS(k) as_[k]
-#elif defined(SS_Q_KEEP)
+#if defined(SS_Q_KEEP)
 #define SS_QS(k) q_all[k]
 #define SS_AS(k) act_all[k]
 #else
@@ -1505,11 +1499,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   {
     float qf[NH], qq[NH];
 #pragma unroll
-#if defined(SS_Q_KEEP) && defined(SS_Q_KEEP_INT)
-    for (int k = 0; k < NH; ++k) { qf[k] = SS_QDF(k); qq[k] = q_all[k]; }
-#else
-    for (int k = 0; k < NH; ++k) { qf[k] = SS_QDF(k); qq[k] = L.s(S_Q + k); }
-#endif
+    for (int k = 0; k < NH; ++k) { qf[k] = SS_QDF(k); qq[k] = L.s(S_Q + k); }   // (q kept in registers to here: slower)
     SS_MEMBAR();
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
