@@ -33,8 +33,8 @@ def _worker(rank, port, ret):
         acts = torch.rand((env.num_envs, 21), generator=gen) * 2 - 1       # same global actions on every rank
         obs, rew, done, _ = env.step(acts)
         out.append(np.concatenate([obs.numpy(), rew.numpy()[:, None], done.numpy()[:, None].astype(np.float32)], 1))
-    # benchmark path too
-    o2, r2, d2 = env.rollout_random(2, t0=100)
+    # benchmark path too: more steps than the ring of gather buffers is deep (asynchronous collectives, batched waits)
+    o2, r2, d2 = env.rollout_random(11, t0=100)
     out.append(np.concatenate([o2.numpy(), r2.numpy()[:, None], d2.numpy()[:, None].astype(np.float32)], 1))
     ret[rank] = out
     dist.barrier()
@@ -55,7 +55,7 @@ def test_two_rank_sharding_equals_single_process():
         acts = (torch.rand((N_LOCAL * WORLD, 21), generator=gen) * 2 - 1).numpy()
         ob, r, d, _ = o.step(acts)
         ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
-    for k in range(2):
+    for k in range(11):
         ob, r, d, _ = o.step(o.random_actions(100 + k))
     ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
     for rank in range(WORLD):
