@@ -67,3 +67,22 @@ def test_mirror_indices_are_a_permutation_free_partition():
     assert max(neg_o) < 60 and max(neg_a) < 21
     # swapped joints are the same in the action and in both joint blocks of the observation
     assert [i - 6 for i in r_o[:9]] == list(r_a) and [i - 27 for i in r_o[9:18]] == list(r_a)
+
+
+def test_header_is_plain_c_and_usable_without_python(tmp_path):
+    """include/steppingstone.h compiles as C99 and a dlopen client (tests/host/abi_c_client.c) reaches the library;
+    without a GPU ss_create answers SS_ERR_NO_DEVICE and an error message (no CPU fallback)."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from steppingstone_amd import build
+    lib = build.build()
+    exe = str(tmp_path / "abi_c_client")
+    src = os.path.join(ROOT, "tests", "host", "abi_c_client.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", src, "-o", exe, "-ldl"])
+    out = subprocess.run([exe, lib], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "version 1" in out.stdout and "obs_dim 60 act_dim 21" in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "create rc -3" in out.stdout and "no CPU fallback" in out.stdout
