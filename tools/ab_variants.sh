@@ -7,7 +7,7 @@ mkdir -p var
 names=()
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -fno-signed-zeros -ffp-contract=on $flags \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -fno-signed-zeros -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp $flags \
     -Rpass-analysis=kernel-resource-usage steppingstone_amd/csrc/ss_api.hip -o var/libss_$name.so 2> var/$name.res || { echo "build $name failed"; exit 1; }
   printf "%-12s " "$name"; grep -A12 "step_kernelINS_13ModelWalker3DELb1" var/$name.res | grep -E "VGPRs:|AGPRs|ScratchSize" | sed 's/.*remark: *//; s/ \[-R.*//' | tr '\n' ' '; echo
   names+=("$name")
