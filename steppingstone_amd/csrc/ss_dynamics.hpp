@@ -36,19 +36,8 @@ constexpr float kErp = 0.2f;
 constexpr float kSlop = 0.001f;
 constexpr float kVcorrMax = 2.0f;
 
-// PGS in packed f32 by default (0.0980 vs 0.1027 ms/step); -DSS_PGS_SCALAR selects the scalar point-space sweep,
-// -DSS_PGS_SCALAR -DSS_PGS_TWIST_ROWS the scalar twist-space one
-#ifndef SS_PGS_SCALAR
-#define SS_PGS_PACKED
-#endif
-#ifdef SS_PGS_PACKED
-#define SS_PGS_TWIST_ROWS
-// contact operators by packed unit-impulse recursions (two columns per instruction): 0.0914 vs 0.0928 ms/step with
-// the Omega recursion (-DSS_OMEGA_OPERATORS), which is scalar and one dependent chain
-#ifndef SS_OMEGA_OPERATORS
-#define SS_UNIT_COLUMNS_PACKED
-#endif
-#endif
+// The PGS sweep, the row set-up and the contact operators run in packed f32 (v_pk_fma_f32); the scalar / Omega-recursion
+// variants of rounds 1 (v7) were removed in round 2 -- they are in the git history with their measurements.
 
 constexpr int kWave = 64;
 constexpr int kEnvsPerWave = 32;
@@ -123,10 +112,6 @@ struct JointCache {
   Chol6 L0;
 };
 constexpr int half_pos(int j) { return j <= 7 ? j : j - 5; }   // 13..16 -> 8..11
-// Source-level interleaving of the two independent chains (leg, arm) so that neighbouring instructions belong to
-// different dependency chains: one wavefront per SIMD issues a dependent v_fma every ~7 cycles but independent
-// ones every ~2.5 (tools/probes/issue_probe.hip).  Root -> leaves order and its reverse.
-constexpr int kOrderDown[NH] = {0, 1, 2, 3, 13, 4, 14, 5, 15, 6, 16, 7};
 
 // ---- lane-pair exchange.  Partner data lives in the mirrored world: reflect on receipt.
 // On the device this is a DPP quad_perm [1,0,3,2] move (full VALU rate, no LDS round trip like ds_bpermute).
@@ -184,18 +169,6 @@ SSD void ss_sincos(float x, float& s, float& c) {
   c = ((n + 1) & 2) ? -cc : cc;
 }
 
-template <int B>
-SSD SV vel_get(const Lds& L) {
-  constexpr int o = 6 * (B <= 8 ? B : B - 5);   // bodies 0..8, 14..17 -> 0..12
-  SV v = {{L.av(o + 0), L.av(o + 1), L.av(o + 2)}, {L.av(o + 3), L.av(o + 4), L.av(o + 5)}};
-  return v;
-}
-template <int B>
-SSD void vel_put(const Lds& L, const SV& v) {
-  constexpr int o = 6 * (B <= 8 ? B : B - 5);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { L.av(o + i) = v.w[i]; L.av(o + 3 + i) = v.v[i]; }
-}
 SSD SV base_twist(const Lds& L) {
   SV v = {{L.s(S_VW), L.s(S_VW + 1), L.s(S_VW + 2)}, {L.s(S_VV), L.s(S_VV + 1), L.s(S_VV + 2)}};
   return v;
@@ -317,82 +290,6 @@ SSD SV2 chol6_solve_neg_pair(const Chol6& L, const SV2& b) {
   return x;
 }
 
-// ---- inverse articulated inertia ("Omega") recursion, used for the contact-space operators
-//   Omega_b maps an impulse on body b to the twist change of body b (all joints free):
-//   Omega_0 = (I^A_0)^-1,  Omega_child = P Omega_parent P^T + S D^-1 S^T,  P = (1 - S D^-1 U^T) X_J
-struct OMG {       // [[W, X], [X^T, V]] : w = W n + X f,  v = X^T n + V f
-  Sym3 W;
-  float X[3][3];
-  Sym3 V;
-};
-SSD void sym_full(const Sym3& S, float F[3][3]) {
-  F[0][0] = S.m[0]; F[1][1] = S.m[1]; F[2][2] = S.m[2];
-  F[0][1] = F[1][0] = S.m[3]; F[0][2] = F[2][0] = S.m[4]; F[1][2] = F[2][1] = S.m[5];
-}
-template <class Model, int J>
-SSD OMG omega_step(const JRec& r, const OMG& O) {
-  constexpr int AX = kAxis[J];
-  float Xs[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) Xs[i][j] = O.X[i][j];
-  Sym3 V = O.V;
-  // 1. motion-type shift of the origin by r (parent frame):  X' = X + W K,  V' = V + X^T K - K X'   (K = r x)
-  if constexpr (has_offset<Model, J>()) {
-    float Wf[3][3];
-    sym_full(O.W, Wf);
-    float rcx[3][3], rcxs[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float col[3] = {O.X[0][i], O.X[1][i], O.X[2][i]};
-      cross_r<Model, J>(col, rcx[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float t[3];
-      cross_r<Model, J>(Wf[i], t);
-      Xs[i][0] -= t[0]; Xs[i][1] -= t[1]; Xs[i][2] -= t[2];
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float col[3] = {Xs[0][j], Xs[1][j], Xs[2][j]};
-      cross_r<Model, J>(col, rcxs[j]);
-    }
-    V.m[0] -= rcx[0][0] + rcxs[0][0];
-    V.m[1] -= rcx[1][1] + rcxs[1][1];
-    V.m[2] -= rcx[2][2] + rcxs[2][2];
-    V.m[3] -= rcx[0][1] + rcxs[1][0];
-    V.m[4] -= rcx[0][2] + rcxs[2][0];
-    V.m[5] -= rcx[1][2] + rcxs[2][1];
-  }
-  // 2. into the child orientation: E M E^T with E = R^T, i.e. a rotation by -q
-  OMG o;
-  o.W = rot_sym<AX>(r.cs, -r.sn, O.W);
-  o.V = rot_sym<AX>(r.cs, -r.sn, V);
-  rot_gen<AX>(r.cs, -r.sn, Xs, o.X);
-  // 3. free joint:  (1 - s u^T) Omega (1 - s u^T)^T + s e^T,  s = D^-1 e_AX (angular slot), u = U
-  float Wf[3][3], Vf[3][3];
-  sym_full(o.W, Wf);
-  sym_full(o.V, Vf);
-  float tw[3], tv[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    tw[i] = Wf[i][0] * r.Uw[0] + Wf[i][1] * r.Uw[1] + Wf[i][2] * r.Uw[2] + o.X[i][0] * r.Uv[0] + o.X[i][1] * r.Uv[1] +
-            o.X[i][2] * r.Uv[2];
-    tv[i] = o.X[0][i] * r.Uw[0] + o.X[1][i] * r.Uw[1] + o.X[2][i] * r.Uw[2] + Vf[i][0] * r.Uv[0] + Vf[i][1] * r.Uv[1] +
-            Vf[i][2] * r.Uv[2];
-  }
-  const float alpha = r.Uw[0] * tw[0] + r.Uw[1] * tw[1] + r.Uw[2] * tw[2] + r.Uv[0] * tv[0] + r.Uv[1] * tv[1] + r.Uv[2] * tv[2];
-  const float d = r.Dinv;
-  constexpr int ai = (AX + 1) % 3, aj = (AX + 2) % 3;
-  o.W.template at<AX, ai>() -= d * tw[ai];
-  o.W.template at<AX, aj>() -= d * tw[aj];
-  o.W.template at<AX, AX>() += d * (1.0f + d * alpha - 2.0f * tw[AX]);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) o.X[AX][j] -= d * tv[j];
-  return o;
-}
 
 // Contact-space operators for the column pair (2c, 2c+1): T = K = P_7 ... P_3 (own-foot twist per unit pelvis twist through
 // the unloaded leg; LDS), and by unit impulses on the own foot through the whole tree G (pelvis twist; LDS) and
@@ -498,37 +395,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   SS_PROF(0);
   // LDS round trips (~100 cycles) are fully exposed with one wavefront per SIMD, and the compiler issues each
   // ds_read right before its use: batch the loads of a phase up front / prefetch one joint ahead instead.
-#ifndef SS_VEL_LDS      // body twists in registers (AGPR-parked by the compiler): 0.1095 vs 0.1113 ms/step through LDS
-  SV velr[13];
-#define SS_VEL_PUT(b, v) velr[(b) <= 8 ? (b) : (b) - 5] = v
-#define SS_VEL_GET(b) velr[(b) <= 8 ? (b) : (b) - 5]
-#else
-#define SS_VEL_PUT(b, v) vel_put<b>(L, v)
-#define SS_VEL_GET(b) vel_get<b>(L)
-#endif
-#ifndef SS_QDF_LDS       // free joint velocities in registers: 0.0871 vs 0.0890 ms/step through LDS
-  float qdfr[NH];
+  float qdfr[NH];              // free joint velocities
 #define SS_QDF(k) qdfr[k]
-#else
-#define SS_QDF(k) L.s(S_QDF + (k))
-#endif
-  float qd_all[NH];
-#ifndef SS_Q_RELOAD     // joint angles and actions stay in registers through pass 2 (0.0852 vs 0.0857 ms/step)
-#define SS_Q_KEEP
-#endif
-#ifdef SS_Q_KEEP
-  float q_all[NH], act_all[NH];
+  float qd_all[NH], q_all[NH], act_all[NH];
   {
 #pragma unroll
     for (int k = 0; k < NH; ++k) { q_all[k] = L.s(S_Q + k); qd_all[k] = L.s(S_QD + k); act_all[k] = L.s(S_ACT + k); }
     SS_MEMBAR();
-#else
-  {
-    float q_all[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) { q_all[k] = L.s(S_Q + k); qd_all[k] = L.s(S_QD + k); }
-    SS_MEMBAR();
-#endif
     static_for<0, NH>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       ss_sincos(q_all[k], jc.r[k].sn, jc.r[k].cs);
@@ -536,7 +409,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   }
   SS_PROF(1);
 
-#ifndef SS_ABA_SCALAR
   // ================= leg joints 3..6 and arm joints 13..16 as float pairs {leg, arm} (ss_pair.hpp) =================
   // Same axes, same massless/massive pattern: one v_pk instruction serves both chains.  Spine joints 0..2 and the
   // ankle (joint 7) stay scalar.  Topology relied on (asserted): arm on the torso, leg on the pelvis, pelvis on the spine.
@@ -576,13 +448,8 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     }
     SS_PROF(2);
     // ---- pass 2: articulated inertias, leaves -> root
-#if defined(SS_Q_KEEP)
 #define SS_QS(k) q_all[k]
 #define SS_AS(k) act_all[k]
-#else
-#define SS_QS(k) L.s(S_Q + (k))
-#define SS_AS(k) L.s(S_ACT + (k))
-#endif
     // explicit joint torque and implicit diagonal of joint j (PHYSICS.md 3.1)
     auto joint_tau = [&](auto Jc, float q, float qd, float act, float& tau, float& Dadd) {
       constexpr int j = decltype(Jc)::value;
@@ -828,176 +695,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       acc_scalar(std::integral_constant<int, 7>{}, sv_half(pp, 0), vfoot);
     }
   }
-#else   // SS_ABA_SCALAR: every joint on its own (leg and arm chains interleaved at source level)
-  // ---- pass 1: velocities (kept in LDS; each chain's predecessor stays in registers)
-  {
-    const SV v0 = base_twist(L);
-    SV prev_leg = v0, prev_arm = v0;                    // spine+leg chain, arm chain
-    static_for<0, NH>([&](auto Ic) {
-      constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1, ax = kAxis[j];
-      constexpr bool arm = j >= 13;
-      SV v = xmotion<Model, j>(jc.r[k].cs, jc.r[k].sn, arm ? prev_arm : prev_leg);
-      v.w[ax] += qd_all[k];
-      SS_VEL_PUT(b, v);
-      if constexpr (arm) prev_arm = v; else prev_leg = v;
-    });
-  }
-  SS_MEMBAR();
-  SS_PROF(2);
-
-  // ---- pass 2: articulated inertias, leaves -> root over the half-tree
-  ABI acc[NB];
-  SV pacc[NB];
-  struct JIn { SV vb; float q, a; };
-  auto jin_load = [&](auto Ic) {
-    constexpr int j = kOrderDown[decltype(Ic)::value], k = half_pos(j), b = j + 1;
-    JIn r;
-    r.vb = SS_VEL_GET(b);
-    r.q = L.s(S_Q + k);
-    r.a = L.s(S_ACT + k);
-    return r;
-  };
-  JIn jnext = jin_load(std::integral_constant<int, NH - 1>{});
-  static_rfor<NH - 1, 0>([&](auto Ic) {
-    constexpr int idx = decltype(Ic)::value;
-    constexpr int j = kOrderDown[idx], k = half_pos(j), b = j + 1, p = kParent[j], ax = kAxis[j];
-    constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-    constexpr bool leaf = first_child_half(b) < 0;
-    constexpr bool massive = Model::mass[b] != 0.f;
-    const JIn jin = jnext;
-    if constexpr (idx > 0) {
-      jnext = jin_load(std::integral_constant<int, (idx > 0 ? idx - 1 : 0)>{});
-      SS_MEMBAR();                                    // keep the prefetch above this joint's arithmetic
-    }
-    const SV vb = jin.vb;
-    ABI I;
-    SV pA;
-    if constexpr (leaf) {
-      I = abi_body<Model, b>();
-      pA = body_bias<Model, b>(vb);
-    } else {
-      I = acc[b];
-      pA = pacc[b];
-      if constexpr (massive) {
-        abi_add_body<Model, b>(I);
-        SV pb = body_bias<Model, b>(vb);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { pA.w[i] += pb.w[i]; pA.v[i] += pb.v[i]; }
-      }
-    }
-    // joint torque (explicit part) and implicit diagonal, PHYSICS.md 3.1
-    constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
-    constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j];
-    constexpr float tq = Model::torque[j];
-    float q = jin.q, qd = qd_all[k];
-    float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
-    bool lim = viol != 0.f;
-    float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
-    float tau_m = power * tq * jin.a;
-    float tau = tau_m - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
-    float Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
-    // U = I S
-    JRec& r = jc.r[k];
-    r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
-    r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
-    r.Dinv = SS_RCP(r.Uw[ax] + Dadd);
-    r.u = tau - pA.w[ax];
-    const float* Uw = r.Uw;
-    const float* Uv = r.Uv;
-    // Ia = I - U Dinv U^T
-    float sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
-    float sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
-    I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
-    I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
-    I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
-    I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
-    // c = v x S qd : only components ai, aj are non-zero
-    float cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
-    float cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
-    float du = r.Dinv * r.u;
-    SV pa;
-    {
-      const Sym3 &A = I.A, &C = I.C;
-      float Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
-      float Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-        pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
-        pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
-      }
-    }
-    ABI Ip = xinertia<Model, j>(r.cs, r.sn, I);
-    SV pp = xforce<Model, j>(r.cs, r.sn, pa);
-    // limbs hang off the pelvis (legs) and the torso (arms): add the partner limb's contribution, mirrored, with a
-    // commutative (mine + partner) sum so that both lanes get bit-identical totals
-    if constexpr (j == 3 || j == 13) {
-      ABI Io = xchg_abi(Ip);
-      SV po = xchg_sv(pp);
-      abi_add(Ip, Io);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { pp.w[i] += po.w[i]; pp.v[i] += po.v[i]; }
-    }
-    if constexpr (b == first_child_half(p)) {   // the arm (body 14) reaches the torso before the spine (body 1)
-      acc[p] = Ip;
-      pacc[p] = pp;
-    } else {
-      abi_add(acc[p], Ip);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { pacc[p].w[i] += pp.w[i]; pacc[p].v[i] += pp.v[i]; }
-    }
-  });
-  SS_PROF(3);
-
-  // ---- base (redundant in both lanes)
-  SV a0;
-  {
-    const SV v0 = base_twist(L);
-    ABI I0 = acc[0];
-    abi_add_body<Model, 0>(I0);
-    SV pb = body_bias<Model, 0>(v0);
-    SV p0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { p0.w[i] = pacc[0].w[i] + pb.w[i]; p0.v[i] = pacc[0].v[i] + pb.v[i]; }
-    float M[6][6];
-    abi_dense(I0, M);
-    jc.L0 = chol6(M);
-    a0 = chol6_solve_neg(jc.L0, p0);
-  }
-  SS_PROF(4);
-
-  // ---- pass 3: accelerations -> free velocities (to LDS), leg and arm chains interleaved, twists prefetched
-  {
-    SV prev_leg = a0, prev_arm = a0;
-    auto vget = [&](auto Ic) { constexpr int b = kOrderDown[decltype(Ic)::value] + 1; return SS_VEL_GET(b); };
-    SV vnext = vget(std::integral_constant<int, 0>{});
-    static_for<0, NH>([&](auto Ic) {
-      constexpr int idx = decltype(Ic)::value;
-      constexpr int j = kOrderDown[idx], k = half_pos(j), ax = kAxis[j];
-      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-      constexpr bool arm = j >= 13;
-      const JRec& r = jc.r[k];
-      const SV vb = vnext;
-      if constexpr (idx + 1 < NH) {
-        vnext = vget(std::integral_constant<int, (idx + 1 < NH ? idx + 1 : 0)>{});
-        SS_MEMBAR();
-      }
-      SV a = xmotion<Model, j>(r.cs, r.sn, arm ? prev_arm : prev_leg);
-      float qd = qd_all[k];
-      a.w[ai] += qd * vb.w[aj]; a.w[aj] -= qd * vb.w[ai];
-      a.v[ai] += qd * vb.v[aj]; a.v[aj] -= qd * vb.v[ai];
-      float dotv = r.Uw[0] * a.w[0] + r.Uw[1] * a.w[1] + r.Uw[2] * a.w[2] + r.Uv[0] * a.v[0] + r.Uv[1] * a.v[1] +
-                   r.Uv[2] * a.v[2];
-      float qdd = r.Dinv * (r.u - dotv);
-      a.w[ax] += qdd;
-      if constexpr (arm) prev_arm = a; else prev_leg = a;
-      SS_QDF(k) = qd + h * qdd;
-    });
-  }
-#endif  // SS_ABA_SCALAR
   float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
   float Rb[3][3];
   quat_rot(quat, Rb);
@@ -1106,11 +803,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #endif
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     float ul[NH];
-    // Contact-space operators by the inverse-articulated-inertia (Omega) recursion, ~2.4 k instructions where six
-    // unit-impulse recursions through the tree take ~4.0 k:
-    //   T = K = P_7 ... P_3 (columns by the unloaded down pass; LDS), G = Omega_pelvis K^T (LDS),
-    //   Lambda_own = Omega_foot (stays in registers: only the row set-up below reads it)
-#if defined(SS_UNIT_COLUMNS_PACKED) && defined(SS_PGS_PACKED)
     ssf2 Lc[6][3];                     // column b of Lambda_own as three pairs
     if constexpr (HELPERS > 0) {
 #pragma unroll
@@ -1125,87 +817,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         for (int i = 0; i < 3; ++i) { Lc[2 * c][i] = lp.a[i]; Lc[2 * c + 1][i] = lp.b[i]; }
       });
     }
-#else
-    // T columns, two per pass (columns 2c and 2c+1 share every instruction)
-#pragma unroll
-    for (int cpair = 0; cpair < 3; ++cpair) {
-      SV2 d;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        d.w[m] = ssf2{2 * cpair == m ? 1.f : 0.f, 2 * cpair + 1 == m ? 1.f : 0.f};
-        d.v[m] = ssf2{2 * cpair == m + 3 ? 1.f : 0.f, 2 * cpair + 1 == m + 3 ? 1.f : 0.f};
-      }
-      static_for<3, 8>([&](auto Jc) { d = imp_down_pair<Model, decltype(Jc)::value>(jc, d); });
-      L.q2(kLdsT + (2 * cpair) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
-      L.q2(kLdsT + (2 * cpair) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
-      L.q2(kLdsT + (2 * cpair) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
-      L.q2(kLdsT + (2 * cpair + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
-      L.q2(kLdsT + (2 * cpair + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
-      L.q2(kLdsT + (2 * cpair + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
-    }
-    OMG O;
-    {   // Omega_0 = (L L^T)^-1, column by column
-      float inv[6][6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        SV e;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { e.w[m] = (i == m) ? -1.f : 0.f; e.v[m] = (i == m + 3) ? -1.f : 0.f; }
-        SV x = chol6_solve_neg(jc.L0, e);
-        inv[0][i] = x.w[0]; inv[1][i] = x.w[1]; inv[2][i] = x.w[2]; inv[3][i] = x.v[0]; inv[4][i] = x.v[1]; inv[5][i] = x.v[2];
-      }
-      O.W.m[0] = inv[0][0]; O.W.m[1] = inv[1][1]; O.W.m[2] = inv[2][2]; O.W.m[3] = inv[0][1]; O.W.m[4] = inv[0][2]; O.W.m[5] = inv[1][2];
-      O.V.m[0] = inv[3][3]; O.V.m[1] = inv[4][4]; O.V.m[2] = inv[5][5]; O.V.m[3] = inv[3][4]; O.V.m[4] = inv[3][5]; O.V.m[5] = inv[4][5];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) O.X[a][b] = inv[a][3 + b];
-    }
-    static_for<0, 3>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
-    {   // G = Omega_pelvis K^T : column i = Omega_pelvis applied to the pelvis force K^T e_i = (row i of K); packed f32
-      float Wf[3][3], Vf[3][3];
-      sym_full(O.W, Wf);
-      sym_full(O.V, Vf);
-      ssf2 Oc[6][3];                     // column b of Omega_pelvis = [[W, X], [X^T, V]] as three pairs
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        Oc[b][0] = ssf2{Wf[0][b], Wf[1][b]}; Oc[b][1] = ssf2{Wf[2][b], O.X[b][0]}; Oc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
-        Oc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Oc[3 + b][1] = ssf2{O.X[2][b], Vf[0][b]}; Oc[3 + b][2] = ssf2{Vf[1][b], Vf[2][b]};
-      }
-      float Kc[6][6];                    // Kc[m][i] = K[i][m] = (T column m)[i]
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        float2 c0 = L.q2(kLdsT + m * 3 + 0), c1 = L.q2(kLdsT + m * 3 + 1), c2 = L.q2(kLdsT + m * 3 + 2);
-        Kc[m][0] = c0.x; Kc[m][1] = c0.y; Kc[m][2] = c1.x; Kc[m][3] = c1.y; Kc[m][4] = c2.x; Kc[m][5] = c2.y;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        ssf2 g[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) g[q] = Oc[0][q] * ssf2{Kc[0][i], Kc[0][i]};
-#pragma unroll
-        for (int b = 1; b < 6; ++b)
-#pragma unroll
-          for (int q = 0; q < 3; ++q) g[q] = Oc[b][q] * ssf2{Kc[b][i], Kc[b][i]} + g[q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) L.q2(kLdsG + i * 3 + q) = make_float2(g[q].x, g[q].y);
-      }
-    }
-    static_for<3, 8>([&](auto Jc) { O = omega_step<Model, decltype(Jc)::value>(jc.r[decltype(Jc)::value], O); });
-#ifdef SS_PGS_PACKED
-    ssf2 Lc[6][3];                     // column b of Lambda_own = [[W, X], [X^T, V]] as three pairs
-    {
-      float LW[3][3], LV[3][3];
-      sym_full(O.W, LW);
-      sym_full(O.V, LV);
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        Lc[b][0] = ssf2{LW[0][b], LW[1][b]}; Lc[b][1] = ssf2{LW[2][b], O.X[b][0]}; Lc[b][2] = ssf2{O.X[b][1], O.X[b][2]};
-        Lc[3 + b][0] = ssf2{O.X[0][b], O.X[1][b]}; Lc[3 + b][1] = ssf2{O.X[2][b], LV[0][b]}; Lc[3 + b][2] = ssf2{LV[1][b], LV[2][b]};
-      }
-    }
-#endif
-#endif
     SS_PROF(7);
     // own-foot twist under the free velocities
     float V[6];
@@ -1219,7 +830,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
     }
-#ifdef SS_PGS_PACKED
     // rows (registers, float pairs): per (corner, direction) y = Lambda_own w and the Jacobian row w = (c x dir, dir),
     // 1/A, b_n.  Inactive corners keep finite rows (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
     ssf2 rYp[12][3], rWp[12][3];
@@ -1265,66 +875,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         });
       });
     }
-#else
-    // rows (registers): per (corner, direction) y_own[6] = Lambda_own w, dir[3], 1/A, b_n ; all-zero for inactive corners
-#ifdef SS_PGS_TWIST_ROWS
-    float rY[12][6], rD[12][6], rIA[12], rB[4];     // rD = the full contact Jacobian row w = (c x dir, dir)
-#else
-    float rY[12][6], rD[12][3], rIA[12], rB[4];
-#endif
-    {
-      float LW[3][3], LV[3][3];
-      sym_full(O.W, LW);
-      sym_full(O.V, LV);
-      static_for<0, 4>([&](auto Kc) {
-        constexpr int k = decltype(Kc)::value;
-        constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-        const bool on = (active >> k) & 1;
-        const int sl = (cslot >> (2 * k)) & 3;
-        float n[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) n[i] = on ? L.s(S_STN + sl * 3 + i) : (i == 2 ? 1.f : 0.f);
-        float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
-        float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
-        t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
-        float t2[3];
-        cross(n, t1, t2);
-        float corr = fmaxf(pen[k] - kSlop, 0.f);
-        rB[k] = on ? fminf(kErp * corr * (1.0f / kH), kVcorrMax) : 0.f;
-        static_for<0, 3>([&](auto Dc) {
-          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
-          const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
-          float w[6];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) w[3 + c] = Rf[0][c] * dir[0] + Rf[1][c] * dir[1] + Rf[2][c] * dir[2];
-          w[0] = cy * w[5] - cz * w[4];
-          w[1] = cz * w[3] - cx * w[5];
-          w[2] = cx * w[4] - cy * w[3];
-          float y[6];
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            y[a] = LW[a][0] * w[0] + LW[a][1] * w[1] + LW[a][2] * w[2] + O.X[a][0] * w[3] + O.X[a][1] * w[4] + O.X[a][2] * w[5];
-            y[3 + a] = O.X[0][a] * w[0] + O.X[1][a] * w[1] + O.X[2][a] * w[2] + LV[a][0] * w[3] + LV[a][1] * w[4] + LV[a][2] * w[5];
-          }
-          float A = 0.f;
-#pragma unroll
-          for (int l = 0; l < 6; ++l) A += w[l] * y[l];
-#pragma unroll
-          for (int l = 0; l < 6; ++l) rY[row][l] = on ? y[l] : 0.f;
-#ifdef SS_PGS_TWIST_ROWS
-#pragma unroll
-          for (int c = 0; c < 6; ++c) rD[row][c] = on ? w[c] : 0.f;
-#else
-#pragma unroll
-          for (int c = 0; c < 3; ++c) rD[row][c] = on ? w[3 + c] : 0.f;
-#endif
-          rIA[row] = on ? SS_RCP(A) : 0.f;
-        });
-      });
-    }
-#endif   // SS_PGS_PACKED rows
     SS_PROF(8);
-#ifdef SS_PGS_PACKED
     // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
     // the rows y = Lambda w and w, the sweep's wrench and the G / T columns are held as three float pairs each
     float lam[4][3];
@@ -1384,90 +935,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int i = 0; i < 3; ++i) Wp[i] += dWp[i];
     }
     SV W = {{Wp[0].x, Wp[0].y, Wp[1].x}, {Wp[1].y, Wp[2].x, Wp[2].y}};
-#else
-    // projected Gauss-Seidel on the own foot; Jacobi coupling to the other foot once per sweep
-    float lam[4][3];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lam[k][0] = lam[k][1] = lam[k][2] = 0.f;
-    SV W = zero;                     // accumulated own-foot wrench
-    constexpr float mu = Model::friction;
-#pragma unroll 1
-    for (int it = 0; it < kPgsIters; ++it) {
-      SV dW = zero;
-      float* Vw = V;
-      float* Vv = V + 3;
-#ifdef SS_PGS_TWIST_ROWS
-      static_for<0, 12>([&](auto Rc) {
-        constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
-        float vrel = rD[row][0] * V[0] + rD[row][1] * V[1] + rD[row][2] * V[2] + rD[row][3] * V[3] + rD[row][4] * V[4] +
-                     rD[row][5] * V[5];
-        float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
-        if constexpr (d == 0) {
-          ln = fmaxf(ln, 0.f);
-        } else {
-          float lim = mu * lam[k][0];
-          ln = fminf(fmaxf(ln, -lim), lim);
-        }
-        float dl = ln - lam[k][d];
-        lam[k][d] = ln;
-#pragma unroll
-        for (int l = 0; l < 6; ++l) V[l] += rY[row][l] * dl;
-        dW.w[0] += rD[row][0] * dl; dW.w[1] += rD[row][1] * dl; dW.w[2] += rD[row][2] * dl;
-        dW.v[0] += rD[row][3] * dl; dW.v[1] += rD[row][4] * dl; dW.v[2] += rD[row][5] * dl;
-      });
-      (void)Vw; (void)Vv;
-#else
-      static_for<0, 4>([&](auto Kc) {
-        constexpr int k = decltype(Kc)::value;
-        constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-        float fc[3] = {0.f, 0.f, 0.f};
-        static_for<0, 3>([&](auto Dc) {
-          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
-          float px = Vv[0] + Vw[1] * cz - Vw[2] * cy;
-          float py = Vv[1] + Vw[2] * cx - Vw[0] * cz;
-          float pz = Vv[2] + Vw[0] * cy - Vw[1] * cx;
-          float vrel = rD[row][0] * px + rD[row][1] * py + rD[row][2] * pz;
-          float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
-          if constexpr (d == 0) {
-            ln = fmaxf(ln, 0.f);
-          } else {
-            float lim = mu * lam[k][0];
-            ln = fminf(fmaxf(ln, -lim), lim);
-          }
-          float dl = ln - lam[k][d];
-          lam[k][d] = ln;
-          Vw[0] += rY[row][0] * dl; Vw[1] += rY[row][1] * dl; Vw[2] += rY[row][2] * dl;
-          Vv[0] += rY[row][3] * dl; Vv[1] += rY[row][4] * dl; Vv[2] += rY[row][5] * dl;
-          fc[0] += rD[row][0] * dl; fc[1] += rD[row][1] * dl; fc[2] += rD[row][2] * dl;
-        });
-        dW.v[0] += fc[0]; dW.v[1] += fc[1]; dW.v[2] += fc[2];
-        dW.w[0] += cy * fc[2] - cz * fc[1];
-        dW.w[1] += cz * fc[0] - cx * fc[2];
-        dW.w[2] += cx * fc[1] - cy * fc[0];
-      });
-#endif
-      // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
-      // this foot through T
-      const float dw[6] = {dW.w[0], dW.w[1], dW.w[2], dW.v[0], dW.v[1], dW.v[2]};
-      SV dp = zero;
-#pragma unroll
-      for (int l = 0; l < 6; ++l) {
-        float2 c0 = L.q2(kLdsG + l * 3 + 0), c1 = L.q2(kLdsG + l * 3 + 1), c2 = L.q2(kLdsG + l * 3 + 2);
-        dp.w[0] += c0.x * dw[l]; dp.w[1] += c0.y * dw[l]; dp.w[2] += c1.x * dw[l];
-        dp.v[0] += c1.y * dw[l]; dp.v[1] += c2.x * dw[l]; dp.v[2] += c2.y * dw[l];
-      }
-      const SV dpo = xchg_sv(dp);
-      const float dpv[6] = {dpo.w[0], dpo.w[1], dpo.w[2], dpo.v[0], dpo.v[1], dpo.v[2]};
-#pragma unroll
-      for (int l = 0; l < 6; ++l) {
-        float2 c0 = L.q2(kLdsT + l * 3 + 0), c1 = L.q2(kLdsT + l * 3 + 1), c2 = L.q2(kLdsT + l * 3 + 2);
-        V[0] += c0.x * dpv[l]; V[1] += c0.y * dpv[l]; V[2] += c1.x * dpv[l];
-        V[3] += c1.y * dpv[l]; V[4] += c2.x * dpv[l]; V[5] += c2.y * dpv[l];
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { W.w[i] += dW.w[i]; W.v[i] += dW.v[i]; }
-    }
-#endif   // SS_PGS_PACKED
     SS_PROF(9);
     // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down
 #ifndef SS_ABLATE_FINAL
