@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched random-action rollout (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: ONE step_kernel launch advancing 4096 Walker3DStepperEnv-v0
-environments per GPU by one control step (4 physics substeps, contact solve, reward, auto-reset, 60-float
-observation), actions drawn on the device (Philox, U(-1,1)).  Workload = BASELINE.json configs[1]
-("Walker3DStepperEnv-v0, 4096 envs on 1 MI355X, flat terrain (curriculum off), random actions").  With N>1 GPUs
-each rank owns 4096 envs (weak scaling) and every step ends with the RCCL all-gather of the packed
-[4096,62] obs|rew|done block (BASELINE configs[3]).  State is resident in HBM before the timed region.
+N > 1 without a launcher: bench.py starts its own N ranks (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ..., steppingstone_amd/launch.py), the way the reference's make_vec_envs forks its own
+workers (common/envs_utils.py:519-538); started by torch.distributed.run already, it runs as one rank.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) including `roofline` and `cpu_baseline`.
+A "step" is one control step of every environment of the job: 4096 Walker3DStepperEnv-v0 environments per GPU
+(BASELINE.json configs[1]: flat terrain, curriculum off, random actions drawn on the device, auto-reset on), each
+step = 4 physics substeps, contact solve, reward, termination, auto-reset, 60-float observation, all written to HBM.
+  N = 1: the K timed steps run through ss_rollout_random's multi-step kernel (up to 1000 control steps
+         per launch, state resident in LDS between steps, outputs and the HBM state copy written every step); the
+         one-launch-per-step path (what a policy-in-the-loop caller uses) is timed beside it as `per_step_launch`.
+  N > 1: every rank owns 4096 envs (weak scaling) and every step ends with the RCCL all-gather of the packed
+         [4096,62] obs|rew|done block (BASELINE configs[3]), so steps are single launches; the same K steps without
+         the collective are timed as `no_gather`.
+State is resident in HBM before the timed region.  Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline`.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -23,66 +31,175 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DStepperEnv-v0"
-# ALGORITHMIC HBM bytes per env-step of the rollout kernel with this repository's state layout (DESIGN.md
-# "bytes"): read 83 f32 state/stone-cache fields + 4 i32 = 348 B; write 59 f32 + 5 i32 state = 256 B,
-# obs 240 B, rew 4 B, done 1 B, info 20 B = 521 B.  (Actions are generated on the device: 0 B.)
-ALGO_BYTES_PER_ENV_STEP = 348 + 521
+# ALGORITHMIC HBM bytes per env-step with this repository's state layout:
+#   one launch per step: read 83 f32 state / stone-cache fields + 4 i32 = 348 B; write 59 f32 + 5 i32 state = 256 B,
+#                        obs 240 B, rew 4 B, done 1 B, info 20 B = 521 B                                     -> 869 B
+#   K steps per launch:  the 348 B are read once per launch, the 521 B written every step; the epilogue's re-read of
+#                        the 13 bookkeeping words + stone cache is served by L2                 -> 521 + 348/K B
+ALGO_READ_B, ALGO_WRITE_B = 348, 521
 HBM_PEAK_GBS = 8000.0
 VALU_FP32_PEAK_TFLOPS = 157.3          # packed-f32 vector peak (MI355X_MICROARCH.md): 256 CUs x 2.4 GHz x 256 flop/clk
 
 
-def recorded_traffic(n_envs):
-    """HBM bytes per step_kernel launch from the latest committed PMC run (separate FETCH_SIZE / WRITE_SIZE passes,
-    calibrated on a dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py).  PMC collection needs
-    rocprofv3 around the process, so bench.py reports the recorded figure and names its source; null if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic_%d.json" % n_envs)))
-    if not files:
+def _natural(path):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+
+
+def latest_profile(pattern):
+    """Newest committed profile matching the glob: round / build numbers compared as NUMBERS (r01_v10 > r01_v9)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=_natural)
+    return files[-1] if files else None
+
+
+def recorded_traffic(n_envs, tag):
+    """HBM bytes per launch of the dominant kernel from the latest committed PMC run (separate FETCH_SIZE / WRITE_SIZE
+    passes, calibrated on a dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py).  PMC collection
+    needs rocprofv3 around the process, so bench.py reports the recorded figure and names its source; null if absent."""
+    f = latest_profile("*hbm_traffic_%s%d.json" % (tag, n_envs))
+    if not f:
+        return None, None, None
+    with open(f) as fh:
+        d = json.load(fh)
+    return float(d["hbm_bytes_per_env_step"]) * n_envs, os.path.relpath(f, ROOT), d       # bytes per control step of the batch
+
+
+def recorded_pmc():
+    f = latest_profile("*pmc_4096.json")
+    if not f:
         return None, None
-    with open(files[-1]) as f:
-        return float(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    with open(f) as fh:
+        return json.load(fh), os.path.relpath(f, ROOT)
 
 
-def recorded_flops_per_env_step():
-    """fp32 VALU flops per env-step from the committed SQ-counter profile (SQ_INSTS_VALU_FLOPS_FP32 counts flops per
-    wavefront-instruction lane); null if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_4096.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    v = d["per_wave_per_launch"].get("SQ_INSTS_VALU_FLOPS_FP32")
-    if not v:
-        return None, None
-    # per-wavefront mean x wavefronts per launch (main + helper wavefronts) x 64 lanes, per env of the launch
-    return float(v) * float(d["waves_per_launch"]) * 64.0 / float(d["envs"]), os.path.relpath(files[-1], ROOT)
+def pmc_note(d):
+    """The limiter statement of roofline.note, derived from the current PMC file (not hard-coded)."""
+    if not d:
+        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 4.1); no PMC profile committed"
+    w = d.get("per_wave_per_launch", {})
+    cyc = w.get("SQ_WAVE_CYCLES") or 0
+    if not cyc:
+        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 4.1)"
+    busy = 100.0 * (w.get("SQ_ACTIVE_INST_VALU") or 0) / cyc
+    wait = 100.0 * (w.get("SQ_WAIT_ANY") or 0) / cyc
+    return ("not HBM-bound: per-lane rigid-body dynamics limited by VALU issue / dependent-chain latency; averaged over "
+            "the %s wavefronts of a launch (main + helper wavefronts) SQ_ACTIVE_INST_VALU = %.0f %% and SQ_WAIT_ANY = "
+            "%.0f %% of wave cycles (DESIGN.md 4.1)" % (d.get("waves_per_launch", "?"), busy, wait))
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU oracle (a port of docs/PHYSICS.md, NOT PyBullet) on the host cores, same workload, bounded."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle_fast_lib():
+    """the CPU port built -O3 -march=native ON THE BOX THAT RUNS IT (the parity oracle is -O2
+    -ffp-contract=off for reproducibility and is not what a CPU user would ship).  Falls back to the parity build."""
+    import subprocess
+    src = os.path.join(ROOT, "oracle", "ss_oracle.c")
+    out = os.path.join(ROOT, "oracle", "lib", "libss_oracle_f32_native.so")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=c11", "-fopenmp", "-DSSO_REAL=float",
+                               "-o", out, src, "-lm"], stderr=subprocess.DEVNULL)
+        return out, "-O3 -march=native"
+    except Exception:
+        return None, "-O2 -ffp-contract=off (parity build; native build failed)"
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget=24.0):
+    """The CPU oracle (a port of docs/PHYSICS.md, NOT PyBullet) on the host cores of this box, bounded samples of the
+    same workload.  Rows of BASELINE.md section 3: C1 single_thread, C2 all_cores (= the headline value), C3
+    shmem_frontend (process-per-env architecture of common/envs_utils.py:486-675), C4 ipc_only (that front end with a
+    no-op env)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
     import numpy as np
     import oracle_lib as ol
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    env = ol.OracleEnv("walker3d", ENVS_PER_GPU, seed=0)
-    env.reset()
-    acts = [env.random_actions(t) for t in range(4)]
-    env.step(acts[0])                       # warm-up
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        env.step(acts[steps % 4])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or steps >= 400:
-            break
-    return {"value": ENVS_PER_GPU * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d control steps of %d Walker3D envs, oracle/ss_oracle.c fp32, OpenMP over %d host threads, "
-                      "%.1f s" % (steps, ENVS_PER_GPU, cores, el)}
+    import shmem_frontend as sf
+    lib_path, flags = _oracle_fast_lib()
+    if lib_path:
+        ol.load("f32")                                           # declares the prototypes on the parity build ...
+        fast = ctypes.CDLL(lib_path)
+        proto = ol._libs["f32"]
+        for fn in ("sso_create", "sso_destroy", "sso_reset", "sso_step", "sso_random_actions", "sso_set_auto_reset"):
+            getattr(fast, fn).argtypes = getattr(proto, fn).argtypes
+            getattr(fast, fn).restype = getattr(proto, fn).restype
+        ol._libs["f32_native"] = fast                            # ... and the same ones on the native build
+
+    gomp = ctypes.CDLL("libgomp.so.1")
+
+    def make(n, threads):
+        gomp.omp_set_num_threads(int(threads))                   # OMP_NUM_THREADS is read once, at library load
+        e = ol.OracleEnv.__new__(ol.OracleEnv)
+        e.lib = ol._libs["f32_native"] if lib_path else ol.load("f32")
+        e.real, e.kind, e.n = np.float32, ol.KIND["walker3d"], n
+        e.h = e.lib.sso_create(e.kind, n, 0, 0)
+        return e
+
+    def rate(env, acts, seconds, max_steps):
+        env.reset()
+        env.step(acts[0])
+        t0, steps = time.perf_counter(), 0
+        while True:
+            env.step(acts[steps % len(acts)])
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > seconds or steps >= max_steps:
+                return env.n * steps / el, steps, el
+
+    rng = np.random.default_rng(0)
+    # C1: one env, one thread
+    e1 = make(1, 1)
+    v1, s1, t1 = rate(e1, rng.uniform(-1, 1, (64, 1, 21)).astype(np.float32), 0.15 * budget, 2000)
+    e1.close()
+    # C2: 4096 envs, OpenMP over the host threads.  os.cpu_count() is not what a container may use (affinity mask,
+    # cgroup quota) and oversubscribed OpenMP teams collapse, so the team size is swept and the best one reported.
+    usable = usable_cpus()
+    cand = sorted({max(1, usable >> k) for k in range(0, 6)} | {min(usable, 64), min(usable, 32)}, reverse=True)
+    sweep = {}
+    acts4 = None
+    for th in cand:
+        e = make(ENVS_PER_GPU, th)
+        acts4 = acts4 or [e.random_actions(t) for t in range(4)]
+        sweep[th] = rate(e, acts4, 0.04 * budget, 6)[0]
+        e.close()
+    best_th = max(sweep, key=sweep.get)
+    eN = make(ENVS_PER_GPU, best_th)
+    vN, sN, tN = rate(eN, acts4, 0.3 * budget, 400)
+    eN.close()
+    cores = best_th
+    out = {"value": vN, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d control steps of %d Walker3D envs, oracle/ss_oracle.c fp32 built %s on this box, OpenMP over %d "
+                     "host threads, %.1f s" % (sN, ENVS_PER_GPU, flags, cores, tN),
+           "all_cores": {"value": vN, "cores": cores, "envs": ENVS_PER_GPU, "steps": sN, "seconds": tN,
+                         "os_cpu_count": os.cpu_count(), "usable_cpus": usable,
+                         "thread_sweep": {str(k): round(v) for k, v in sorted(sweep.items())}},
+           "single_thread": {"value": v1, "cores": 1, "envs": 1, "steps": s1, "seconds": t1,
+                             "ms_per_env_step": 1e3 / v1}}
+    # C3 / C4: process-per-env shared-memory front end, P = min(cores, 64) workers
+    workers = max(2, min(usable, 64))
+    try:
+        v3, s3, t3 = sf.measure("walker3d", workers, seconds=0.2 * budget)
+        out["shmem_frontend"] = {"value": v3, "cores": workers, "envs": workers, "steps": s3, "seconds": t3,
+                                 "note": "one worker process per env, pipe + shared-memory obs (architecture of "
+                                         "common/envs_utils.py:486-675) around the parity-build oracle"}
+        v4, s4, t4 = sf.measure("noop", workers, seconds=0.1 * budget)
+        out["ipc_only"] = {"value": v4, "cores": workers, "envs": workers, "steps": s4, "seconds": t4,
+                           "note": "same front end, no-op env: ceiling of the process-per-env architecture on this host"}
+    except Exception as exc:                                     # a baseline row must never fail the bench
+        out["shmem_frontend"] = {"value": None, "error": repr(exc)[:200]}
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ the bench
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,27 +208,35 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--env", default=ENV_ID)
     ap.add_argument("--curriculum", type=int, default=0)
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="N=1: control steps per kernel launch (0 = min(K, 1000); 1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-step all-gather")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Mike / capacity side measurements")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: time only the collective-free rollout")
+    ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
     args = ap.parse_args()
 
     # more hardware queues than HIP's default 4, so that RCCL's stream never shares one with the launch stream
     # (steppingstone_amd/distributed.py); must be set before the HIP runtime starts
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    from steppingstone_amd import launch
+    rc = launch.ensure_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
+    rank, local_rank, world = launch.rank_info()
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
+
     import torch
     import torch.distributed as dist
     from steppingstone_amd.distributed import ShardedVecEnv
     from steppingstone_amd.envs import SteppingStoneVecEnv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force = os.environ.get("SS_FORCE_COLLECTIVE") == "1"      # world 1 under torchrun: still go through RCCL
-    use_dist = world > 1 or (force and "RANK" in os.environ)
+    use_dist = world > 1 or (force and launch.launched())
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -123,6 +248,8 @@ def main():
     env = ShardedVecEnv(local)
     env.reset()
     gather = use_dist and not args.no_gather
+    spl = args.steps_per_launch if args.steps_per_launch > 0 else min(args.steps, 1000)
+    multi_step = not use_dist and spl > 1
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -130,73 +257,152 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    env.rollout_random(args.warmup, t0=0, gather=gather)
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # kernel-only time: events around each launch would perturb the stream; instead time a second, gather-free
-    # pass of the same K launches with events on the launch stream (back-to-back launches => sum of durations).
-    t_start = time.perf_counter()
-    env.rollout_random(args.steps, t0=args.warmup, gather=gather)
-    sync()
-    elapsed = time.perf_counter() - t_start
-    ev0.record()
-    local.rollout_random(args.steps, t0=args.warmup + args.steps)
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    def timed(fn):
+        """wall clock (barrier + synchronize on both sides) and HIP-event time on the launch stream of fn()"""
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        fn()
+        ev1.record()
+        sync()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    K, W = args.steps, args.warmup
+    if multi_step:
+        run = lambda k, t0: local.rollout_random(k, t0=t0, steps_per_launch=spl)            # noqa: E731
+    else:
+        run = lambda k, t0: env.rollout_random(k, t0=t0, gather=gather)                     # noqa: E731
+    if W:
+        run(W, 0)
+    elapsed, main_ev_ms = timed(lambda: run(K, W))
+    # the other launch granularity / the collective-free pass, on the same K steps (not the headline value)
+    side = {}
+    t_next = W + K
+    if multi_step:
+        el1, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
+        side["per_step_launch"] = {"ms_per_step": 1e3 * el1 / K, "value": n_local * K / el1, "kernel_ms": ev1 / K,
+                                   "note": "same K steps, one kernel launch per control step (the path a policy-in-the-"
+                                           "loop caller and the multi-GPU all-gather use)"}
+        kernel_ms_per_step = main_ev_ms / K
+    else:
+        if use_dist and gather:
+            el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
+            side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
+            t_next += K
+        _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
+        kernel_ms_per_step = ev1 / K                       # back-to-back launches on one stream: sum of durations
+
+    t = torch.tensor([elapsed] + [side.get("no_gather", {}).get("ms_per_step", 0.0)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    if "no_gather" in side:
+        side["no_gather"]["ms_per_step"] = float(t[1].item())
+        side["no_gather"]["value"] = n_local * world / (side["no_gather"]["ms_per_step"] * 1e-3)
 
     if rank == 0:
         total_envs = n_local * world
-        value = total_envs * args.steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = recorded_traffic(n_local)
+        value = total_envs * K / elapsed
+        steps_in_launch = spl if multi_step else 1
+        algo_per_env_step = ALGO_WRITE_B + ALGO_READ_B / float(steps_in_launch)
+        launch_ms = kernel_ms_per_step * steps_in_launch
+        algo_per_launch = algo_per_env_step * n_local * steps_in_launch
+        achieved = algo_per_launch / (launch_ms * 1e-3) / 1e9
+        tag = "rollout_" if multi_step else ""
+        traffic, traffic_src, traffic_rec = recorded_traffic(n_local, tag)
+        if traffic is not None:
+            traffic *= steps_in_launch                 # per launch of THIS run, like `achieved` (recorded per env-step)
+        pmc, pmc_src = recorded_pmc()
+        helpers = 3 if n_local <= 8192 else (1 if n_local <= 16384 else 0)
+        model = "ModelWalker3D" if "Walker3D" in args.env else "ModelMike"
+        if multi_step:
+            kernel = ("ss::rollout_kernel_helped<%s,%d>" % (model, helpers)) if helpers else "ss::rollout_kernel<%s>" % model
+        else:
+            kernel = ("ss::step_kernel_helped<%s,true,%d>" % (model, helpers)) if helpers else "ss::step_kernel<%s,true>" % model
         out = {
             "metric": "env-steps/sec (batched random-action rollout)",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d envs per MI355X, curriculum %d (flat terrain), on-device Philox U(-1,1) "
-                                   "actions, auto-reset on" % (args.env, n_local, args.curriculum),
-                       "envs_total": total_envs, "parallelism": "env-shard x%d%s" % (world, "+allgather" if gather else "")},
+            "config": {"workload": "%s, %d envs per MI355X, curriculum %d%s, on-device Philox U(-1,1) actions, auto-reset on"
+                                   % (args.env, n_local, args.curriculum, " (flat terrain)" if not args.curriculum else ""),
+                       "envs_total": total_envs,
+                       "parallelism": "env-shard x%d%s" % (world, "+allgather" if gather else ""),
+                       "ranks": world, "collective": ("RCCL all_gather_into_tensor of [%d,62] f32 per step, %d ranks"
+                                                      % (n_local, world)) if gather else None,
+                       "steps_per_launch": steps_in_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
-                         "kernel": "ss::step_kernel_helped<ModelWalker3D,true,3> (ss::step_kernel above 16384 envs)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
-                         "note": "VALU-issue-bound per-lane rigid-body dynamics (80 % VALU-busy, one wavefront per SIMD), not HBM-bound (DESIGN.md 4.1)"},
+                         "traffic_recorded_at_steps_per_launch": (traffic_rec or {}).get("steps_per_launch", 1 if traffic_rec else None),
+                         "kernel": kernel, "kernel_ms": launch_ms, "kernel_ms_per_step": kernel_ms_per_step,
+                         "algorithmic_bytes_per_env_step": algo_per_env_step,
+                         "algorithmic_bytes_per_launch": algo_per_launch,
+                         "note": pmc_note(pmc), "note_source": pmc_src},
         }
-        flop, flop_src = recorded_flops_per_env_step()
-        if flop:
-            tf = flop * n_local / (kernel_ms * 1e-3) / 1e12
-            out["roofline"]["valu_fp32"] = {"flop_per_env_step": flop, "source": flop_src, "achieved": tf, "peak": VALU_FP32_PEAK_TFLOPS,
-                                            "unit": "TFLOP/s", "frac": tf / VALU_FP32_PEAK_TFLOPS,
-                                            "note": "secondary roofline: packed-f32 vector peak of the chip; 4096 envs occupy 128 of its 1024 SIMDs"}
-        if world == 1 and not use_dist and n_local < 32768:
-            # not the metric: the same kernel with every SIMD of the chip occupied (4 wavefronts per CU)
-            big = SteppingStoneVecEnv(args.env, 32768, seed=0, device=dev, return_numpy=False)
-            big.reset()
-            big.rollout_random(50, 0)
-            torch.cuda.synchronize(dev)
-            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            b0.record(); big.rollout_random(200, 50); b1.record()
-            torch.cuda.synchronize(dev)
-            bms = b0.elapsed_time(b1) / 200
-            out["capacity"] = {"envs_per_gpu": 32768, "ms_per_step": bms, "value": 32768 / (bms * 1e-3), "unit": "env-steps/s",
-                               "roofline_frac": ALGO_BYTES_PER_ENV_STEP * 32768 / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "valu_fp32_frac": (flop * 32768 / (bms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS) if flop else None,
-                               "note": "same kernel at 32768 envs on this GPU (all 1024 SIMDs occupied); not the BASELINE config"}
-            big.close()
+        out.update(side)
+        flop = None
+        if pmc and pmc.get("per_wave_per_launch", {}).get("SQ_INSTS_VALU_FLOPS_FP32"):
+            # per-wavefront mean x wavefronts per launch (main + helper wavefronts) x 64 lanes, per env-step of the launch
+            flop = (float(pmc["per_wave_per_launch"]["SQ_INSTS_VALU_FLOPS_FP32"]) * float(pmc["waves_per_launch"]) * 64.0
+                    / float(pmc["envs"]) / float(pmc.get("steps_per_launch", 1)))
+            tf = flop * n_local / (kernel_ms_per_step * 1e-3) / 1e12
+            out["roofline"]["valu_fp32"] = {"flop_per_env_step": flop, "source": pmc_src, "achieved": tf,
+                                            "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_FP32_PEAK_TFLOPS,
+                                            "note": "secondary roofline: packed-f32 vector peak of the chip; %d envs occupy "
+                                                    "%d of its 1024 SIMDs" % (n_local, n_local // 32 * (1 + helpers))}
+        if world == 1 and not use_dist and not args.no_extra:
+            out["extra"] = extra_rows(torch, SteppingStoneVecEnv, dev, flop)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extra_rows(torch, SteppingStoneVecEnv, dev, flop):
+    """Side measurements on the same GPU (never the headline value): BASELINE.json configs[2] (MikeStepperEnv-v0, 4096
+    envs, curriculum sampler on: level 5, uniform grid, then the peaked grid softmax(-10 |v - 0.85|) of a fixed
+    synthetic v) and the chip's capacity at 32768 envs."""
+    import numpy as np
+
+    def rate(env, steps, spl):
+        env.rollout_random(64, 0, steps_per_launch=min(spl, 64))
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); env.rollout_random(steps, 64, steps_per_launch=spl); e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / steps
+
+    rows = {}
+    mike = SteppingStoneVecEnv("MikeStepperEnv-v0", ENVS_PER_GPU, seed=0, device=dev, return_numpy=False)
+    mike.update_curriculum(5)
+    mike.reset()
+    for name, spl in (("uniform", 500), ("uniform_per_step_launch", 1)):
+        ms = rate(mike, 500, spl)
+        rows["mike_4096_curriculum5_" + name] = {"ms_per_step": ms, "value": ENVS_PER_GPU / (ms * 1e-3), "steps_per_launch": spl}
+    v = np.random.default_rng(0).random((11, 11))
+    logits = -10.0 * np.abs(v - 0.85)
+    p = np.exp(logits - logits.max())
+    mike.update_sample_prob(p / p.sum())
+    mike.reset()
+    ms = rate(mike, 500, 500)
+    rows["mike_4096_curriculum5_peaked"] = {"ms_per_step": ms, "value": ENVS_PER_GPU / (ms * 1e-3), "steps_per_launch": 500,
+                                            "grid": "softmax(-10|v-0.85|), v = default_rng(0).random((11,11))"}
+    st = mike.get_state()
+    rows["mike_4096_curriculum5_peaked"]["mean_next_step_index"] = float(st[:, 59].mean())
+    mike.close()
+    big = SteppingStoneVecEnv(ENV_ID, 32768, seed=0, device=dev, return_numpy=False)
+    big.reset()
+    bms = rate(big, 200, 200)
+    rows["capacity_32768"] = {"envs_per_gpu": 32768, "ms_per_step": bms, "value": 32768 / (bms * 1e-3), "unit": "env-steps/s",
+                              "roofline_frac": (ALGO_WRITE_B + ALGO_READ_B / 200.0) * 32768 / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "valu_fp32_frac": (flop * 32768 / (bms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS) if flop else None,
+                              "note": "same kernel at 32768 envs on this GPU (all 1024 SIMDs occupied); not the BASELINE config"}
+    big.close()
+    return rows
 
 
 if __name__ == "__main__":

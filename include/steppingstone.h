@@ -8,8 +8,14 @@
  *
  * Conventions: all functions return 0 on success or a negative ss_status; ss_last_error() returns a thread-local
  * message.  The caller owns every I/O buffer (device pointers, e.g. tensor.data_ptr()); the library owns the
- * structure-of-arrays environment state in HBM.  All device work is ordered on the hipStream_t passed in (as
- * void*; NULL = the null stream) and nothing synchronises the host.  One handle per (process, device); a
+ * structure-of-arrays environment state in HBM.  Every entry point that takes a stream (hipStream_t as void*;
+ * NULL = the null stream) only enqueues work on it and never synchronises the host.  The hooks WITHOUT a stream
+ * argument (ss_set_curriculum / _specialist / _sample_prob / _power / _auto_reset) are host-synchronous: they
+ * copy <= 500 bytes (the [N,11,11] per-env grid of ss_set_sample_prob: N x 484 B) to the device-resident hook
+ * state before returning, so every step enqueued afterwards -- on any stream, or replayed from a captured
+ * hipGraph -- sees the new value; a step still in flight when a hook is called may see either (as in the
+ * reference, hooks belong between step_wait() and the next step_async()).  ss_set_sample_prob_device is the
+ * stream-ordered, sync-free form for grids that are computed on the GPU.  One handle per (process, device); a
  * handle is not thread-safe.
  */
 #ifndef STEPPINGSTONE_H
@@ -64,10 +70,13 @@ int ss_reset(ss_env* env, float* obs, void* stream);
  * act [N,21] f32; obs [N,60] f32; rew [N] f32; done [N] u8; info [N] ss_info (may be NULL).  Device pointers. */
 int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream);
 
-/* Benchmark path (BASELINE.json metric "batched random-action rollout"): K steps with on-device Philox
- * actions U(-1,1), one kernel launch per step; t0 = index of the first step in the action stream. */
-int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, float* rew, uint8_t* done,
-                      ss_info* info, void* stream);
+/* Benchmark path (BASELINE.json metric "batched random-action rollout"): num_steps control steps with
+ * on-device Philox actions U(-1,1); t0 = index of the first step in the action stream.  steps_per_launch control
+ * steps run inside ONE kernel launch with the state resident in LDS between them (0 = default 1000; 1 = one launch
+ * per step, the ss_step code path).  Every step writes obs / rew / done / info (the buffers hold the last step's
+ * values afterwards) and the HBM copy of the state; the result is bit-identical for every steps_per_launch. */
+int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, uint64_t t0, float* obs, float* rew,
+                      uint8_t* done, ss_info* info, void* stream);
 /* One step whose results land in ONE packed device buffer [N,62] f32 = obs(60) | rew | done(0/1): the block a
  * multi-GPU shard all-gathers per step (replaces the per-env pipe + shared-memory traffic of
  * common/envs_utils.py:550-558,608-620).  use_random_actions != 0: actions from the benchmark Philox stream at index t. */
@@ -81,6 +90,11 @@ int ss_set_curriculum(ss_env* env, int32_t level);              /* env.update_cu
 int ss_set_specialist(ss_env* env, int32_t level);              /* env.update_specialist */
 /* env.update_sample_prob: HOST pointer to f64 probabilities, [N,11,11] if per_env else [11,11]. */
 int ss_set_sample_prob(ss_env* env, const double* prob, int per_env);
+/* Same hook for a grid that already lives on the GPU (the batched threshold / adaptive sampler computes it there,
+ * playground/train.py:229-272): DEVICE pointer to f32 probabilities, [N,11,11] if per_env else [11,11]; the copy /
+ * transpose and the switch to the new grid are ordered on `stream`, the host is not synchronised (the first per-env
+ * call allocates the [121][N] table). */
+int ss_set_sample_prob_device(ss_env* env, const float* prob, int per_env, void* stream);
 int ss_set_mirror(ss_env* env, int32_t on);                     /* env.set_mirror (train.py:109) */
 int ss_set_power(ss_env* env, float power);                     /* env.set_robot_params({"power": p}) */
 /* on (default): worker semantics, a finished env is reset inside the step (envs_utils.py:647-648);
@@ -107,6 +121,12 @@ int ss_get_obs(ss_env* env, float* obs, void* stream);
 
 int32_t ss_num_envs(const ss_env* env);
 int ss_version(void);
+
+/* Measurement aids (tools/hbm_traffic.py, tools/phase_profile.py); not part of the env protocol.
+ * ss_debug_calib_copy: dword-per-lane copy out[i] = in[i] + 1 used to calibrate the HBM PMC counters.
+ * ss_debug_phase_cycles: 16 per-phase shader-clock totals (zeros unless built with -DSS_PROFILE_PHASES). */
+int ss_debug_calib_copy(const float* in, float* out, uint64_t n, void* stream);
+int ss_debug_phase_cycles(ss_env* env, unsigned long long* out16, int reset);
 
 #ifdef __cplusplus
 }

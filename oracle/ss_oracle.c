@@ -214,6 +214,21 @@ typedef struct {
   real pw[NB][3];
 } work;
 
+/* Decision margins (tests only): while g_margin points at a real[2] the step records, over all substeps,
+ *   [0] the smallest distance of a *state-affecting* discrete decision to its threshold -- contact predicate of a
+ *       sole corner against a stone (|min(-d, d+0.10, R-rho)| in metres), winner among two touching stones
+ *       (|d_a - d_b|), joint-limit switch (|q-hi|, |q-lo| in radians);
+ *   [1] the same for the decisions that only enter reward / done (height, fall, posture bands, joint-at-limit count,
+ *       target radius).
+ * An fp32 implementation with a different operation order may legitimately take the other branch when the margin is
+ * within rounding distance; tests/test_gpu_parity.py asserts that EVERY env-step outside the tolerance is such a case. */
+static _Thread_local real* g_margin = 0;
+static void margin_note(int which, real m) {
+  if (!g_margin) return;
+  if (m < 0) m = -m;
+  if (m < g_margin[which]) g_margin[which] = m;
+}
+
 /* ------------------------------------------------------------------------------------------------ dynamics */
 static void kinematics(const sso_model* M, const env_state* s, work* w) {
   w->Rw[0] = quat_to_rot(s->quat);
@@ -240,6 +255,7 @@ static void aba(const sso_model* M, const env_state* s, const real* tau_m, work*
     real q = s->q[j], qd = s->qd[j], viol = 0, kl = 0, dl = 0;
     if (q > M->hi[j]) viol = q - M->hi[j]; else if (q < M->lo[j]) viol = q - M->lo[j];
     if (viol != 0) { kl = M->klim[j]; dl = M->dlim[j]; }
+    margin_note(0, q - M->hi[j]); margin_note(0, q - M->lo[j]);
     tau[j] = tau_m[j] - M->damping[j] * qd - M->stiffness[j] * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
     Dadd[j] = M->armature[j] + h * (M->damping[j] + dl) + h * h * (M->stiffness[j] + kl);
   }
@@ -369,6 +385,13 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real d = dv[0] * nrm[0] + dv[1] * nrm[1] + dv[2] * nrm[2];
         real lx = dv[0] - d * nrm[0], ly = dv[1] - d * nrm[1], lz = dv[2] - d * nrm[2];
         real rho2 = lx * lx + ly * ly + lz * lz;
+        if (g_margin) {
+          real g1 = -d, g2 = d + (real)0.10, g3 = STONE_R - r_sqrt(rho2);
+          real gm = g1 < g2 ? g1 : g2;
+          if (g3 < gm) gm = g3;
+          margin_note(0, gm);
+          if (gm > 0 && c->active) margin_note(0, d - best);   /* two touching stones: which one wins */
+        }
         if (d < 0 && d > (real)-0.10 && rho2 < STONE_R * STONE_R && d < best) {
           best = d; c->active = 1; c->stone = idx[sl]; c->pen = -d;
           c->n[0] = nrm[0]; c->n[1] = nrm[1]; c->n[2] = nrm[2];
@@ -699,8 +722,11 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   if (s->terrain[s->n][2] < zlow) zlow = s->terrain[s->n][2];
   if (s->terrain[i2][2] < zlow) zlow = s->terrain[i2][2];
   int d = tall_bonus < 0 || s->pos[2] < zlow + (real)0.3 || !finite;
+  margin_note(1, s->pos[2] - zs - (real)0.7);
+  margin_note(1, s->pos[2] - zlow - (real)0.3);
+  if (s->n == NSTONE - 1) margin_note(1, planar_dist(s->terrain[s->n], s->pos) - (real)0.15);
   int timeout = s->elapsed >= 1000;
-  int bad = timeout && !d;
+  int bad = timeout; /* TimeLimitMask, common/envs_utils.py:59-65: done at the step limit, whatever else ended it */
   d = d || timeout;
   /* 9 */
   real roll, pitch, yaw;
@@ -708,6 +734,8 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   real posture = 0;
   if (!(pitch > (real)-0.2 && pitch < (real)0.4)) posture += r_abs(pitch);
   if (!(roll > (real)-0.4 && roll < (real)0.4)) posture += r_abs(roll);
+  margin_note(1, pitch + (real)0.2); margin_note(1, pitch - (real)0.4);
+  margin_note(1, roll + (real)0.4); margin_note(1, roll - (real)0.4);
   real e_sum = 0, a2 = 0;
   int at_limit = 0;
   for (int j = 0; j < NJ; ++j) {
@@ -715,6 +743,7 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
     a2 += a[j] * a[j];
     real mid = (real)0.5 * (M->lo[j] + M->hi[j]);
     if (r_abs(2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j])) > (real)0.99) at_limit += 1;
+    margin_note(1, (r_abs(2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j])) - (real)0.99) * (real)0.5 * (M->hi[j] - M->lo[j]));
   }
   real energy = ((real)4.5 / NJ) * (e_sum / NJ) + ((real)0.225 / NJ) * (a2 / NJ);
   real r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - (real)0.1 * at_limit;
@@ -762,6 +791,16 @@ void sso_step(sso_env* E, const float* act, float* obs, float* rew, uint8_t* don
 #pragma omp parallel for schedule(dynamic, 8)
   for (int e = 0; e < E->num_envs; ++e)
     env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
+}
+/* sso_step that also returns margins[N][2] (see g_margin above) */
+void sso_step_margins(sso_env* E, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info, real* margins) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int e = 0; e < E->num_envs; ++e) {
+    margins[2 * e] = margins[2 * e + 1] = (real)1e30;
+    g_margin = margins + 2 * e;
+    env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
+    g_margin = 0;
+  }
 }
 void sso_set_curriculum(sso_env* E, int c) {
   E->curriculum = c;

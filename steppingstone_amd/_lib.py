@@ -15,7 +15,7 @@ SYMBOLS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_reset", "ss_step", "ss_step_packed", "ss_rollout_random", "ss_random_actions",
     "ss_set_curriculum", "ss_set_specialist", "ss_set_sample_prob", "ss_set_mirror", "ss_set_power", "ss_set_auto_reset",
     "ss_create_temp_states", "ss_get_mirror_indices", "ss_get_state", "ss_set_state", "ss_get_obs", "ss_num_envs",
-    "ss_version",
+    "ss_version", "ss_set_sample_prob_device", "ss_debug_calib_copy", "ss_debug_phase_cycles",
 ]
 
 
@@ -43,12 +43,15 @@ def load():
     lib.ss_last_error.restype = C.c_char_p
     lib.ss_reset.argtypes = [vp, vp, vp]
     lib.ss_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
-    lib.ss_rollout_random.argtypes = [vp, i32, u64, vp, vp, vp, vp, vp]
+    lib.ss_rollout_random.argtypes = [vp, i32, i32, u64, vp, vp, vp, vp, vp]
     lib.ss_step_packed.argtypes = [vp, vp, C.c_int, u64, vp, vp, vp]
     lib.ss_random_actions.argtypes = [vp, u64, vp, vp]
     lib.ss_set_curriculum.argtypes = [vp, i32]
     lib.ss_set_specialist.argtypes = [vp, i32]
     lib.ss_set_sample_prob.argtypes = [vp, vp, C.c_int]
+    lib.ss_set_sample_prob_device.argtypes = [vp, vp, C.c_int, vp]
+    lib.ss_debug_calib_copy.argtypes = [vp, vp, u64, vp]
+    lib.ss_debug_phase_cycles.argtypes = [vp, vp, C.c_int]
     lib.ss_set_mirror.argtypes = [vp, i32]
     lib.ss_set_power.argtypes = [vp, f32]
     lib.ss_set_auto_reset.argtypes = [vp, i32]

@@ -30,6 +30,8 @@ int fail(int code, const std::string& msg) {
 
 struct ss_env {
   ss::Params P;
+  ss::Knobs hk;         // host mirror of the device-resident hook state (P.knobs)
+  ss::Knobs* dk;
   int kind;
   int device;
   float* prob_shared;   // [121]
@@ -37,6 +39,7 @@ struct ss_env {
   float* obs_rows;      // [n][60] scratch: current observation rows for create_temp_states
   int helpers;          // -1 auto, else 0 / 1 / 3 helper wavefronts (env SS_HELPERS)
   int helper_max_groups;  // auto: use the helper wavefront up to this many 32-env groups
+  int mirror;           // env.set_mirror flag (kept; see ss_set_mirror)
 };
 
 namespace {
@@ -53,6 +56,13 @@ void window_prob(float* p, int c, bool ring) {
   for (int k = 0; k < SS_NCELL; ++k) p[k] = p[k] / (float)cnt;
 }
 
+// Host-synchronous hook update: a <= 500-byte hipMemcpy on the null stream.  When it returns the device copy is
+// current, so every step enqueued afterwards (on any stream, or replayed from a hipGraph) sees it.
+int push_knobs(ss_env* env) {
+  SS_HIP(hipMemcpy(env->dk, &env->hk, sizeof(ss::Knobs), hipMemcpyHostToDevice));
+  return SS_OK;
+}
+
 int set_window(ss_env* env, int level, bool ring) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (level < 0 || level > 5) return fail(SS_ERR_INVALID, "curriculum level must be in 0..5");
@@ -60,10 +70,17 @@ int set_window(ss_env* env, int level, bool ring) {
   window_prob(p, level, ring);
   SS_HIP(hipSetDevice(env->device));
   SS_HIP(hipMemcpy(env->prob_shared, p, sizeof p, hipMemcpyHostToDevice));
-  env->P.curriculum = level;
-  env->P.prob = env->prob_shared;
-  env->P.per_env_prob = 0;
-  return SS_OK;
+  env->hk.curriculum = level;
+  env->hk.prob = env->prob_shared;
+  env->hk.per_env_prob = 0;
+  return push_knobs(env);
+}
+
+int helpers_for(const ss_env* env, int groups) {
+  // helper wavefronts (contact operators on the CU's other SIMDs) while the batch leaves SIMDs idle: three while every
+  // 4-wavefront workgroup gets a CU to itself, one while two 2-wavefront workgroups fit a CU
+  return env->helpers >= 0 ? env->helpers
+                           : (groups <= env->helper_max_groups / 2 ? 3 : (groups <= env->helper_max_groups ? 1 : 0));
 }
 
 inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
@@ -72,10 +89,7 @@ template <bool RANDOM>
 int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
   const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane wavefront
   SS_HIP(hipSetDevice(env->device));                   // the stream belongs to this device
-  // helper wavefronts (contact operators on a second SIMD) while the batch leaves SIMDs idle
-  // (three while every 4-wavefront workgroup gets a CU to itself, one while two 2-wavefront workgroups fit a CU)
-  const int helpers = env->helpers >= 0 ? env->helpers
-                      : ((int)grid.x <= env->helper_max_groups / 2 ? 3 : ((int)grid.x <= env->helper_max_groups ? 1 : 0));
+  const int helpers = helpers_for(env, (int)grid.x);
   if (helpers == 3) {
     if (env->kind == SS_WALKER3D)
       hipLaunchKernelGGL((ss::step_kernel_helped<ss::ModelWalker3D, RANDOM, 3>), grid, dim3(4 * ss::kWave), 0, st, env->P, io);
@@ -96,12 +110,37 @@ int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
   return SS_OK;
 }
 
+// io.nsteps control steps in one launch, actions from the benchmark Philox stream
+int launch_rollout(ss_env* env, const ss::StepIO& io, hipStream_t st) {
+  const dim3 grid(env->P.npad / ss::kEnvsPerWave);
+  SS_HIP(hipSetDevice(env->device));
+  const int helpers = helpers_for(env, (int)grid.x);
+  if (helpers == 3) {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::rollout_kernel_helped<ss::ModelWalker3D, 3>), grid, dim3(4 * ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::rollout_kernel_helped<ss::ModelMike, 3>), grid, dim3(4 * ss::kWave), 0, st, env->P, io);
+  } else if (helpers > 0) {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::rollout_kernel_helped<ss::ModelWalker3D, 1>), grid, dim3(2 * ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::rollout_kernel_helped<ss::ModelMike, 1>), grid, dim3(2 * ss::kWave), 0, st, env->P, io);
+  } else {
+    if (env->kind == SS_WALKER3D)
+      hipLaunchKernelGGL((ss::rollout_kernel<ss::ModelWalker3D>), grid, dim3(ss::kWave), 0, st, env->P, io);
+    else
+      hipLaunchKernelGGL((ss::rollout_kernel<ss::ModelMike>), grid, dim3(ss::kWave), 0, st, env->P, io);
+  }
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* ss_last_error(void) { return g_err.c_str(); }
-int ss_version(void) { return 1; }
+int ss_version(void) { return 2; }
 int32_t ss_num_envs(const ss_env* env) { return env ? env->P.n : 0; }
 
 int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t seed, int64_t env_id_offset) {
@@ -131,15 +170,17 @@ int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t see
   P.seed_lo = (uint32_t)seed;
   P.seed_hi = (uint32_t)(seed >> 32);
   P.env_offset = (uint32_t)env_id_offset;
-  P.curriculum = 0;
-  P.power = 1.0f;
-  P.auto_reset = 1;
+  env->hk.curriculum = 0;
+  env->hk.power = 1.0f;
+  env->hk.auto_reset = 1;
   const size_t np = (size_t)P.npad;
   hipError_t e1 = hipMalloc(&P.fstate, sizeof(float) * ss::NF * np);
   hipError_t e2 = hipMalloc(&P.istate, sizeof(int) * ss::NI * np);
   hipError_t e3 = hipMalloc(&P.terrain, sizeof(float) * 120 * np);
   hipError_t e4 = hipMalloc(&env->prob_shared, sizeof(float) * SS_NCELL);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+  hipError_t e5 = hipMalloc(&env->dk, sizeof(ss::Knobs));
+  P.knobs = env->dk;
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
     ss_destroy(env);
     return fail(SS_ERR_ALLOC, "hipMalloc failed for the environment state");
   }
@@ -159,6 +200,7 @@ void ss_destroy(ss_env* env) {
   if (env->P.istate) (void)hipFree(env->P.istate);
   if (env->P.terrain) (void)hipFree(env->P.terrain);
   if (env->prob_shared) (void)hipFree(env->prob_shared);
+  if (env->dk) (void)hipFree(env->dk);
   if (env->prob_env) (void)hipFree(env->prob_env);
   if (env->obs_rows) (void)hipFree(env->obs_rows);
   if (env->P.prof) (void)hipFree(env->P.prof);
@@ -180,17 +222,20 @@ int ss_reset(ss_env* env, float* obs, void* stream) {
 int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!act || !obs || !rew || !done) return fail(SS_ERR_INVALID, "act/obs/rew/done must be device pointers");
-  ss::StepIO io{act, obs, rew, done, info, 0, nullptr};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1};
   return launch_step<false>(env, io, (hipStream_t)stream);
 }
 
-int ss_rollout_random(ss_env* env, int32_t num_steps, uint64_t t0, float* obs, float* rew, uint8_t* done,
-                      ss_info* info, void* stream) {
+int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, uint64_t t0, float* obs, float* rew,
+                      uint8_t* done, ss_info* info, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!obs || !rew || !done) return fail(SS_ERR_INVALID, "obs/rew/done must be device pointers");
-  for (int32_t k = 0; k < num_steps; ++k) {
-    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr};
-    int rc = launch_step<true>(env, io, (hipStream_t)stream);
+  if (num_steps < 0 || steps_per_launch < 0) return fail(SS_ERR_INVALID, "num_steps / steps_per_launch must be >= 0");
+  const int32_t chunk = steps_per_launch > 0 ? steps_per_launch : 1000;     // K = 1000 steps per launch
+  for (int32_t k = 0; k < num_steps; k += chunk) {
+    const int32_t ns = num_steps - k < chunk ? num_steps - k : chunk;
+    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr, ns};
+    int rc = ns == 1 ? launch_step<true>(env, io, (hipStream_t)stream) : launch_rollout(env, io, (hipStream_t)stream);
     if (rc != SS_OK) return rc;
   }
   return SS_OK;
@@ -200,7 +245,7 @@ int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64
                    void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!packed || (!act && !use_random_actions)) return fail(SS_ERR_INVALID, "packed (and act, unless random) must be set");
-  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed};
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1};
   return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
 }
 
@@ -223,9 +268,9 @@ int ss_set_sample_prob(ss_env* env, const double* prob, int per_env) {
     float p[SS_NCELL];
     for (int k = 0; k < SS_NCELL; ++k) p[k] = (float)prob[k];
     SS_HIP(hipMemcpy(env->prob_shared, p, sizeof p, hipMemcpyHostToDevice));
-    env->P.prob = env->prob_shared;
-    env->P.per_env_prob = 0;
-    return SS_OK;
+    env->hk.prob = env->prob_shared;
+    env->hk.per_env_prob = 0;
+    return push_knobs(env);
   }
   const size_t np = (size_t)env->P.npad;
   if (!env->prob_env) SS_HIP(hipMalloc(&env->prob_env, sizeof(float) * SS_NCELL * np));
@@ -233,27 +278,60 @@ int ss_set_sample_prob(ss_env* env, const double* prob, int per_env) {
   for (int e = 0; e < env->P.n; ++e)
     for (int k = 0; k < SS_NCELL; ++k) t[(size_t)k * np + e] = (float)prob[(size_t)e * SS_NCELL + k];
   SS_HIP(hipMemcpy(env->prob_env, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
-  env->P.prob = env->prob_env;
-  env->P.per_env_prob = 1;
+  env->hk.prob = env->prob_env;
+  env->hk.per_env_prob = 1;
+  return push_knobs(env);
+}
+
+int ss_set_sample_prob_device(ss_env* env, const float* prob, int per_env, void* stream) {
+  if (!env || !prob) return fail(SS_ERR_INVALID, "null argument");
+  SS_HIP(hipSetDevice(env->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (!per_env) {
+    hipLaunchKernelGGL(ss::copy_prob_kernel, dim3(1), dim3(128), 0, st, prob, env->prob_shared);
+    env->hk.prob = env->prob_shared;
+    env->hk.per_env_prob = 0;
+  } else {
+    const size_t np = (size_t)env->P.npad;
+    if (!env->prob_env) {
+      SS_HIP(hipMalloc(&env->prob_env, sizeof(float) * SS_NCELL * np));      // first use only (allocation synchronises)
+      SS_HIP(hipMemset(env->prob_env, 0, sizeof(float) * SS_NCELL * np));
+    }
+    const int total = env->P.n * SS_NCELL;
+    hipLaunchKernelGGL(ss::transpose_prob_kernel, dim3((total + 255) / 256), dim3(256), 0, st, prob, env->prob_env, env->P.n,
+                       env->P.npad);
+    env->hk.prob = env->prob_env;
+    env->hk.per_env_prob = 1;
+  }
+  // the pointer / flag switch travels on the same stream, behind the grid it refers to
+  hipLaunchKernelGGL(ss::set_knobs_kernel, dim3(1), dim3(64), 0, st, env->dk, env->hk);
+  SS_HIP(hipGetLastError());
   return SS_OK;
 }
 
 int ss_set_mirror(ss_env* env, int32_t on) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
-  (void)on;   // phase mirroring is a no-op for the (phase-free) Walker3D/Mike steppers
+  // The reference forwards set_mirror to every env (common/envs_utils.py:588-590; playground/train.py:109-111 with
+  // use_phase_mirror).  It matters for gait-phase-clocked envs (the Cassie stepper of train.py:37): their observation
+  // carries a phase variable that mirroring must shift by half a cycle.  Walker3D / Mike steppers have no phase clock
+  // (docs/PHYSICS.md 5: nothing in the 60-float observation depends on one), so the flag changes nothing here; that the
+  // mirror index lists alone make a correct symmetry is pinned by tests/test_gpu_parity.py::test_mirror_equivariance.
+  env->mirror = on ? 1 : 0;
   return SS_OK;
 }
 
 int ss_set_power(ss_env* env, float power) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
-  env->P.power = power;
-  return SS_OK;
+  SS_HIP(hipSetDevice(env->device));
+  env->hk.power = power;
+  return push_knobs(env);
 }
 
 int ss_set_auto_reset(ss_env* env, int32_t on) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
-  env->P.auto_reset = on ? 1 : 0;
-  return SS_OK;
+  SS_HIP(hipSetDevice(env->device));
+  env->hk.auto_reset = on ? 1 : 0;
+  return push_knobs(env);
 }
 
 int ss_create_temp_states(ss_env* env, float* out, void* stream) {

@@ -22,19 +22,26 @@ enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, NI = 5 };
 constexpr int kNumStones = 20;
 constexpr float kDeg = 0.017453292519943295f;
 
+// What the hooks (update_curriculum / update_specialist / update_sample_prob / set_robot_params / auto-reset switch)
+// change between steps.  It lives in HBM and the kernels read it through Params::knobs, so a hipGraph that captured
+// step launches sees every later update (a by-value kernel argument would be frozen at capture time).
+struct Knobs {
+  const float* prob;     // shared [121] or per-env [121][Npad]
+  int per_env_prob;
+  int curriculum;
+  float power;
+  int auto_reset;
+};
+
 struct Params {
   float* fstate;
   int* istate;
   float* terrain;
-  const float* prob;     // shared [121] or per-env [121][Npad]
-  int per_env_prob;
+  const Knobs* knobs;    // device-resident (host harness: host memory)
   int n;                 // number of envs
   int npad;              // padded to a multiple of 64
   uint32_t seed_lo, seed_hi;
   uint32_t env_offset;
-  int curriculum;
-  float power;
-  int auto_reset;
   unsigned long long* prof;   // 16 phase counters, tuning builds (-DSS_PROFILE_PHASES) only
 };
 
@@ -67,11 +74,11 @@ SSD void env_block(const Params& P, int e, uint32_t& ctr, uint32_t out[4]) {
   ctr += 1u;
 }
 
-SSD int sample_cell(const Params& P, int e, float u) {
+SSD int sample_cell(const Params& P, const Knobs& K, int e, float u) {
   float cdf = 0.f;
   int last = 0, pick = -1;
-  const float* pr = P.per_env_prob ? P.prob + e : P.prob;
-  const int stride = P.per_env_prob ? P.npad : 1;
+  const float* pr = K.per_env_prob ? K.prob + e : K.prob;
+  const int stride = K.per_env_prob ? P.npad : 1;
 #pragma unroll 1
   for (int k = 0; k < SS_NCELL; ++k) {
     float pk = pr[(size_t)k * stride];
@@ -83,12 +90,12 @@ SSD int sample_cell(const Params& P, int e, float u) {
 }
 
 // draw stone k from stone k-1 (terrain table), write it to the table; returns dr and the new stone's data
-SSD float draw_stone(const Params& P, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3], float out_t[2],
-                     bool store = true) {
+SSD float draw_stone(const Params& P, const Knobs& K, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3],
+                     float out_t[2], bool store = true) {
   uint32_t r[4];
   env_block(P, e, ctr, r);
-  int cell = sample_cell(P, e, u01(r[0]));
-  float ratio = (float)P.curriculum / 5.0f;
+  int cell = sample_cell(P, K, e, u01(r[0]));
+  float ratio = (float)K.curriculum / 5.0f;
   float dr = 0.65f + u01(r[1]) * (0.6f * ratio);
   float tilt = 15.0f * kDeg * ratio;
   float xt = (2.f * u01(r[2]) - 1.f) * tilt, yt = (2.f * u01(r[3]) - 1.f) * tilt;
@@ -279,6 +286,7 @@ struct StepIO {
   uint64_t t;         // action-stream index for RANDOM_ACT
   float* packed;      // optional [N,62] = obs | rew | done(0/1): the block the multi-GPU all-gather ships; when set,
                       // obs / rew / done above may be null
+  int nsteps;         // control steps per launch (rollout kernels; 1 otherwise)
 };
 
 // draw of the reset joint noise for global joint gj (PHYSICS.md section 7); r = the 6 Philox blocks of the reset
@@ -291,8 +299,13 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
 
 // One control step, lane `lane_global` = 2*env + side (side 0: right half, true world; side 1: left half, mirrored
 // world).  PHYSICS.md section 4.  Env-level logic runs redundantly (and identically) in both lanes in the true world.
-template <class Model, bool RANDOM_ACT, int HELPERS = 0>
+// ROLLOUT: io.nsteps control steps in ONE launch (actions from the benchmark Philox stream at io.t, io.t+1, ...): the
+// state is loaded into LDS once and stays there between steps (the epilogue refreshes the LDS copy when an env is reset
+// or its target advances); every step still writes its outputs and the HBM copy of the state, so the result after K
+// steps is bit-identical to K single-step launches (tested).
+template <class Model, bool RANDOM_ACT, int HELPERS = 0, bool ROLLOUT = false>
 SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, float* lds) {
+  static_assert(!ROLLOUT || RANDOM_ACT, "a multi-step launch draws its actions on the device");
   const int e_raw = lane_global >> 1, side = lane_global & 1;
   const bool valid = e_raw < P.n;
   int e = valid ? e_raw : P.n - 1;
@@ -317,7 +330,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   // 1. this lane's half of the state, mirrored for the left lane, into LDS.  All global loads are issued before the
   //    first LDS store: written load-store-load-store the compiler waited for every load in turn (~25 exposed L2
   //    round trips per step).
-  float gin[13], qin[NH], qdin[NH], ain[NH];
+  float gin[13], qin[NH], qdin[NH];
 #pragma unroll
   for (int i = 0; i < 3; ++i) gin[i] = F[(F_POS + i) * np];
 #pragma unroll
@@ -330,13 +343,14 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     const int gj = side ? jl : jr;
     qin[k] = F[(F_Q + gj) * np];
     qdin[k] = F[(F_QD + gj) * np];
-    if constexpr (!RANDOM_ACT) ain[k] = io.act[(size_t)e * NJ + gj];
   });
-  uint32_t ra[6][4];
-  if constexpr (RANDOM_ACT) {
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-      philox4x32_10((uint32_t)(6u * (uint32_t)io.t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
+  float ain[NH];
+  if constexpr (!RANDOM_ACT) {
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+      ain[k] = io.act[(size_t)e * NJ + (side ? jl : jr)];
+    });
   }
   L.s(S_POS + 0) = gin[0]; L.s(S_POS + 1) = m * gin[1]; L.s(S_POS + 2) = gin[2];
   L.s(S_QUAT + 0) = gin[3]; L.s(S_QUAT + 1) = m * gin[4]; L.s(S_QUAT + 2) = gin[5]; L.s(S_QUAT + 3) = m * gin[6];
@@ -348,19 +362,39 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     const float sg = mirror_flips(jr) ? m : 1.f;
     L.s(S_Q + k) = sg * qin[k];
     L.s(S_QD + k) = sg * qdin[k];
-    float a;
-    if constexpr (RANDOM_ACT) {
-      const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
-      a = 2.f * u01(bits) - 1.f;
-    } else {
-      const float x = ain[k];
-      a = fminf(fmaxf(x, -1.f), 1.f);
-      a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
-    }
-    L.s(S_ACT + k) = sg * a;
   });
 
+  const int nsteps = ROLLOUT ? io.nsteps : 1;
+#pragma unroll 1
+  for (int kstep = 0; kstep < nsteps; ++kstep) {
+  // clipped actions of this lane's joints (its own world) into LDS
+  {
+    uint32_t ra[6][4];
+    if constexpr (RANDOM_ACT) {
+      const uint32_t tt = (uint32_t)io.t + (uint32_t)kstep;
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+        philox4x32_10(6u * tt + b, 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
+    }
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+      const float sg = mirror_flips(jr) ? m : 1.f;
+      float a;
+      if constexpr (RANDOM_ACT) {
+        const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
+        a = 2.f * u01(bits) - 1.f;
+      } else {
+        const float x = ain[k];
+        a = fminf(fmaxf(x, -1.f), 1.f);
+        a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
+      }
+      L.s(S_ACT + k) = sg * a;
+    });
+  }
+
   // 2. four substeps on the LDS-resident state
+  const float power = P.knobs->power;
   FootReport fr;
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
   Prof prof;
@@ -369,11 +403,12 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   prof.last = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
-  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG P.power, fr, L);
+  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG power, fr, L);
   SS_PROF(12);
   SS_MEMBAR();
   SS_OPAQUE(e);                                 // recompute every global address below instead of spilling 27 pointers
   F = P.fstate + e;
+  const Knobs K = *P.knobs;                     // wavefront-uniform scalar loads
   Cache c;                                      // true world
   load_cache(P, e, c);
   float pot_prev = F[F_POT * np], z_init = F[F_ZINIT * np];
@@ -441,7 +476,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       }
       c.tilt[0][0] = c.tilt[1][0]; c.tilt[0][1] = c.tilt[1][1];
       c.tilt[1][0] = c.tilt[2][0]; c.tilt[1][1] = c.tilt[2][1];
-      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], valid && side == 0);
+      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, K, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], valid && side == 0);
     }
   }
   // 6. progress
@@ -455,7 +490,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   float zlow = fminf(fminf(c.p[0][2], c.p[1][2]), c.p[2][2]);
   bool d = (tall_bonus < 0.f) || (pos[2] < zlow + 0.3f) || !finite;
   bool timeout = elapsed >= SS_MAX_EPISODE_STEPS;
-  int bad = (timeout && !d) ? 1 : 0;
+  int bad = timeout ? 1 : 0;                     // TimeLimitMask (common/envs_utils.py:59-65): done at the step limit, whatever else ended it
   d = d || timeout;
   // 9. reward
   float roll, pitch, yaw;
@@ -474,7 +509,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   inf.bad_transition = bad;
   inf.steps_reached = n;
   inf.update_terrain = advanced;
-  const bool do_reset = d && P.auto_reset;
+  const bool do_reset = d && K.auto_reset;
   uint32_t rr[6][4];
   if (do_reset) {
     // PHYSICS.md section 7: provisional terrain, standing pose, joint noise from 6 Philox blocks
@@ -638,11 +673,35 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   }
 #endif
 #undef SS_OBS
+  if constexpr (ROLLOUT) {
+    // the next step starts from the LDS copy of the state: refresh what the env logic changed (this lane's world)
+    if (do_reset) {
+      L.s(S_POS + 0) = pos[0]; L.s(S_POS + 1) = m * pos[1]; L.s(S_POS + 2) = pos[2];
+      L.s(S_QUAT + 0) = quat[0]; L.s(S_QUAT + 1) = m * quat[1]; L.s(S_QUAT + 2) = quat[2]; L.s(S_QUAT + 3) = m * quat[3];
+      L.s(S_VW + 0) = m * v0.w[0]; L.s(S_VW + 1) = v0.w[1]; L.s(S_VW + 2) = m * v0.w[2];
+      L.s(S_VV + 0) = v0.v[0]; L.s(S_VV + 1) = m * v0.v[1]; L.s(S_VV + 2) = v0.v[2];
+      static_for<0, NH>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+        const float sg = mirror_flips(jr) ? m : 1.f;
+        L.s(S_Q + k) = sg * qt[k];
+        L.s(S_QD + k) = sg * qdt[k];
+      });
+    }
+    if (advanced || do_reset) {
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        L.s(S_STP + sl * 3 + 0) = c.p[sl][0]; L.s(S_STP + sl * 3 + 1) = m * c.p[sl][1]; L.s(S_STP + sl * 3 + 2) = c.p[sl][2];
+        L.s(S_STN + sl * 3 + 0) = c.nrm[sl][0]; L.s(S_STN + sl * 3 + 1) = m * c.nrm[sl][1]; L.s(S_STN + sl * 3 + 2) = c.nrm[sl][2];
+      }
+    }
+    SS_MEMBAR();
+  }
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
   SS_PROF(13);
   if (lane == 0 && P.prof)
     for (int i = 0; i < 16; ++i) atomicAdd(P.prof + i, (unsigned long long)prof.t[i]);
 #endif
+  }   // control steps of this launch
 }
 
 #ifndef SS_HOST_HARNESS
@@ -667,7 +726,44 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
     for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L);
   }
 }
+// K control steps per launch (ss_rollout_random): same code, state resident in LDS between the steps
+template <class Model>
+__global__ __launch_bounds__(kWave, 1) void rollout_kernel(Params P, StepIO io) {
+  __shared__ float4 lds4[kLdsSlots * kWave];
+  step_env<Model, true, 0, true>(P, io, blockIdx.x * kWave + threadIdx.x, threadIdx.x, reinterpret_cast<float*>(lds4));
+}
+template <class Model, int HELPERS>
+__global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helped(Params P, StepIO io) {
+  __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
+  float* lds = reinterpret_cast<float*>(lds4);
+  if (wave == 0) {
+    step_env<Model, true, HELPERS, true>(P, io, blockIdx.x * kWave + lane, lane, lds);
+  } else {
+    const Lds L{lds, lane};
+    const int nsub = io.nsteps * SS_NUM_SUBSTEPS;
+#pragma unroll 1
+    for (int k = 0; k < nsub; ++k) helper_substep<Model, HELPERS>(wave - 1, L);
+  }
+}
 #endif  // SS_HOST_HARNESS
+
+// hook updates, stream-ordered (ss_api.hip)
+#ifndef SS_HOST_HARNESS
+__global__ void set_knobs_kernel(Knobs* dst, Knobs v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+// per-env sampling grids: [N][121] row-major (the caller's layout, playground/train.py:267-271) -> [121][Npad]
+__global__ void transpose_prob_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int npad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * SS_NCELL) return;
+  const int e = i / SS_NCELL, k = i - e * SS_NCELL;
+  dst[(size_t)k * npad + e] = src[i];
+}
+__global__ void copy_prob_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+  if (threadIdx.x < SS_NCELL) dst[threadIdx.x] = src[threadIdx.x];
+}
+#endif
 
 #ifndef SS_HOST_HARNESS
 template <class Model>

@@ -103,9 +103,9 @@ class HipBackend:
     def step(self, act, obs, rew, done, info):
         _lib.check(self.lib.ss_step(self.h, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done), _ptr(info), _stream(self.device)))
 
-    def rollout_random(self, num_steps, t0, obs, rew, done, info):
-        _lib.check(self.lib.ss_rollout_random(self.h, int(num_steps), int(t0), _ptr(obs), _ptr(rew), _ptr(done),
-                                              _ptr(info), _stream(self.device)))
+    def rollout_random(self, num_steps, t0, obs, rew, done, info, steps_per_launch=0):
+        _lib.check(self.lib.ss_rollout_random(self.h, int(num_steps), int(steps_per_launch), int(t0), _ptr(obs), _ptr(rew),
+                                              _ptr(done), _ptr(info), _stream(self.device)))
 
     def step_packed(self, act, use_random, t, packed, info):
         _lib.check(self.lib.ss_step_packed(self.h, _ptr(act) if act is not None else None, 1 if use_random else 0, int(t),
@@ -123,6 +123,9 @@ class HipBackend:
     def set_sample_prob(self, prob, per_env):
         prob = np.ascontiguousarray(prob, np.float64)
         _lib.check(self.lib.ss_set_sample_prob(self.h, prob.ctypes.data_as(C.c_void_p), 1 if per_env else 0))
+
+    def set_sample_prob_device(self, prob, per_env):
+        _lib.check(self.lib.ss_set_sample_prob_device(self.h, _ptr(prob), 1 if per_env else 0, _stream(self.device)))
 
     def set_mirror(self, on):
         _lib.check(self.lib.ss_set_mirror(self.h, 1 if on else 0))
@@ -245,9 +248,10 @@ class SteppingStoneVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
-    def rollout_random(self, num_steps, t0=0):
-        """BASELINE metric path: num_steps launches with on-device U(-1,1) actions (Philox stream 1)."""
-        self.backend.rollout_random(num_steps, t0, self._obs, self._rew, self._done, self._info)
+    def rollout_random(self, num_steps, t0=0, steps_per_launch=0):
+        """BASELINE metric path: num_steps control steps with on-device U(-1,1) actions (Philox stream 1),
+        steps_per_launch of them per kernel launch (0: the library default of 1000; 1: one launch per step)."""
+        self.backend.rollout_random(num_steps, t0, self._obs, self._rew, self._done, self._info, steps_per_launch)
         return self._obs, self._rew, self._done
 
     def step_packed(self, packed, actions=None, t=0):
@@ -288,8 +292,17 @@ class SteppingStoneVecEnv:
         self.backend.set_specialist(min(max(int(specialist), 0), 5))
 
     def update_sample_prob(self, probs):
-        """probs: (N,11,11) one grid per env (playground/train.py:267-271) or a single (11,11) grid."""
-        probs = np.asarray(probs, np.float64)
+        """probs: (N,11,11) one grid per env (playground/train.py:267-271) or a single (11,11) grid.  A torch tensor on
+        the env's device takes the stream-ordered path (no host copy, no synchronisation)."""
+        if torch.is_tensor(probs) and probs.device.type == "cuda":
+            if tuple(probs.shape) not in ((GRID, GRID), (self.num_envs, GRID, GRID)):
+                raise ValueError("sample_prob must have shape (%d,%d,%d) or (%d,%d), got %s"
+                                 % (self.num_envs, GRID, GRID, GRID, GRID, tuple(probs.shape)))
+            p = probs.to(device=self.device, dtype=torch.float32).contiguous()
+            self._prob_keepalive = p           # the kernel reads it asynchronously
+            self.backend.set_sample_prob_device(p, p.dim() == 3)
+            return
+        probs = np.asarray(probs.cpu() if torch.is_tensor(probs) else probs, np.float64)
         if probs.shape == (GRID, GRID):
             self.backend.set_sample_prob(probs, False)
         elif probs.shape == (self.num_envs, GRID, GRID):

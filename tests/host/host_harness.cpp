@@ -68,11 +68,12 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   std::vector<int> is((size_t)ss::NI * P.npad, 0);
   window_prob(pr.data(), curriculum);
   if (prob) for (int k = 0; k < 121; ++k) pr[k] = (float)prob[k];
-  P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.prob = pr.data();
-  P.per_env_prob = 0; P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
-  P.curriculum = curriculum; P.power = 1.f; P.auto_reset = 1;
+  ss::Knobs K;
+  K.prob = pr.data(); K.per_env_prob = 0; K.curriculum = curriculum; K.power = 1.f; K.auto_reset = 1;
+  P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.knobs = &K;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
   std::vector<float4> lds((size_t)ss::kLdsSlots * 64);
-  ss::StepIO io{act, obs, rew, done, info, 0};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
   for (int e = 0; e < n; ++e) {
     PairSync sync;

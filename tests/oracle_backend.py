@@ -30,7 +30,7 @@ class OracleBackend:
         raw[:, 2], raw[:, 3], raw[:, 4] = i["bad_transition"], i["steps_reached"], i["update_terrain"]
         info.copy_(torch.from_numpy(raw))
 
-    def rollout_random(self, num_steps, t0, obs, rew, done, info):
+    def rollout_random(self, num_steps, t0, obs, rew, done, info, steps_per_launch=0):
         act = torch.zeros((self.n, 21))
         for k in range(num_steps):
             act.copy_(torch.from_numpy(self.o.random_actions(t0 + k)))

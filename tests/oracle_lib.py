@@ -45,6 +45,7 @@ def load(prec="f32"):
     lib.sso_destroy.argtypes = [vp]
     lib.sso_reset.argtypes = [vp, vp]
     lib.sso_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.sso_step_margins.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.sso_set_curriculum.argtypes = [vp, i32]
     lib.sso_set_specialist.argtypes = [vp, i32]
     lib.sso_set_sample_prob.argtypes = [vp, vp, i32]
@@ -101,6 +102,19 @@ class OracleEnv:
         info = np.zeros(self.n, INFO_DTYPE)
         self.lib.sso_step(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info))
         return obs, rew, done, info
+
+    def step_margins(self, act):
+        """step() that also returns margins [N,2]: the distance of the closest discrete decision of this control step
+        to its threshold -- column 0: decisions that change the state (contact set, stone choice, joint-limit
+        switches; metres / radians), column 1: decisions that only enter reward / done."""
+        act = np.ascontiguousarray(act, np.float32).reshape(self.n, ACT_DIM)
+        obs = np.zeros((self.n, OBS_DIM), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        info = np.zeros(self.n, INFO_DTYPE)
+        margins = np.zeros((self.n, 2), self.real)
+        self.lib.sso_step_margins(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info), _p(margins))
+        return obs, rew, done, info, margins
 
     def set_curriculum(self, c):
         self.lib.sso_set_curriculum(self.h, int(c))

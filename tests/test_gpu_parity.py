@@ -4,12 +4,19 @@ same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
 Tolerances (fp32, stated here as required by the task brief):
   * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, done,
     bad_transition, update_terrain): bit-exact;
-  * one control step from an identical injected state (4 substeps, different operation order and libm):
-    |obs| 2e-3 abs on the +-5-clipped observation, state 2e-3 abs / 2e-3 rel, reward 2e-2 abs -- required of
-    >= 99.5 % of env-steps, because a contact that is within rounding of opening/closing legitimately flips the
-    discrete contact set (those env-steps are reported, not hidden);
-  * free-running 1000-step drift is chaotic (contacts make/break) and is characterised, not bounded, beyond the
-    first 5 steps.
+  * one control step from an identical injected state (4 substeps, different operation order, own sincos / reciprocal):
+    every env-step is CLASSIFIED with the oracle itself --
+      flagged   = a state-affecting discrete decision of that step (contact predicate of a sole corner, stone choice,
+                  joint-limit switch; oracle_lib.step_margins) lies within 1e-5 of its threshold, OR the fp32 and the
+                  fp64 build of the oracle's own C code disagree by more than 2.5e-5 on that very step (the step
+                  amplifies fp32 rounding >= 50x: ill-conditioned contact solve);
+      unflagged = everything else (measured 97 % of env-steps): integers bit-exact, |obs| error <= 5e-4 for ALL of
+                  them and <= 1e-4 (the north-star's bound) for >= 99.95 % (measured 99.98 %, 99.9 % within 4e-5),
+                  reward <= 1e-3, state <= 2.5e-3 relative;
+    flagged env-steps (<= 5 %) may take the other branch -- they are counted and reported, and an integer / done
+    mismatch is accepted only on a flagged step (tools/parity_margins.py prints the full table);
+  * free-running drift is chaotic (contacts make/break): characterised against the fp64 build, see
+    tests/test_gpu_branches.py::test_closed_loop_1000_step_drift.
 """
 import os
 import numpy as np
@@ -59,47 +66,63 @@ def test_random_action_stream_is_bit_exact():
 
 
 def _step_parity(env_id, kind, n, steps, seed, curriculum=0):
+    """One control step from identical injected states: HIP kernel vs fp32 oracle, with the fp64 oracle and the
+    oracle's decision margins as the classifier (module docstring).  Returns the per-env-step arrays."""
     g = gpu_env(env_id, n, seed=seed)
     o = ol.OracleEnv(kind, n, seed=seed)
+    o64 = ol.OracleEnv(kind, n, seed=seed, prec="f64")
     if curriculum:
         g.update_curriculum(curriculum)
         o.set_curriculum(curriculum)
+        o64.set_curriculum(curriculum)
     g.reset()
     o.reset()
-    bad = 0
-    worst = dict(obs=0.0, state=0.0, rew=0.0)
-    total = 0
+    o64.reset()
+    rows = {k: [] for k in ("e_obs", "e_state", "e_rew", "ints", "flag")}
     for t in range(steps):
         st = o.get_state()
         g.set_state(st)
+        o64.set_state(st.astype(np.float64))
         a = o.random_actions(t)
-        oo, ro, do, io = o.step(a)
+        o6 = o64.step(a)[0]
+        oo, ro, do, io, mg = o.step_margins(a)
         og, rg, dg, ig = g.step(a)
         sg, so = g.get_state().cpu().numpy(), o.get_state()
         raw = g._info.cpu().numpy()
-        e_obs = np.abs(og - oo).max(axis=1)
-        tol_state = 2e-3 + 2e-3 * np.abs(so)
-        e_state = (np.abs(sg - so) / tol_state).max(axis=1)
-        e_rew = np.abs(rg - ro)
-        ints_ok = (sg[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1) & (dg == do.astype(bool)) & \
-                  (raw[:, 2] == io["bad_transition"]) & (raw[:, 4] == io["update_terrain"])
-        ok = (e_obs < 2e-3) & (e_state < 1.0) & (e_rew < 2e-2) & ints_ok
-        bad += int((~ok).sum())
-        total += n
-        if ok.any():
-            worst["obs"] = max(worst["obs"], float(e_obs[ok].max()))
-            worst["state"] = max(worst["state"], float(e_state[ok].max()))
-            worst["rew"] = max(worst["rew"], float(e_rew[ok].max()))
+        cont = ~do.astype(bool)                                   # a finished env's state is the fresh reset state
+        rows["e_obs"].append(np.abs(og - oo).max(axis=1))
+        rows["e_state"].append(np.where(cont, (np.abs(sg[:, :59] - so[:, :59]) / (1.0 + np.abs(so[:, :59]))).max(axis=1), 0.0))
+        rows["e_rew"].append(np.abs(rg - ro))
+        rows["ints"].append((sg[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1) & (dg == do.astype(bool)) &
+                            (raw[:, 2] == io["bad_transition"]) & (raw[:, 4] == io["update_terrain"]))
+        rows["flag"].append((mg[:, 0] < 1e-5) | (np.abs(oo - o6).max(axis=1) > 2.5e-5))
     g.close()
-    return bad, total, worst
+    return {k: np.concatenate(v) for k, v in rows.items()}
 
 
 @pytest.mark.parametrize("env_id,kind", KINDS)
 def test_single_step_parity_from_injected_state(env_id, kind):
-    bad, total, worst = _step_parity(env_id, kind, n=256, steps=60, seed=11)
-    print("single-step parity %s: %d/%d env-steps outside tolerance; worst in-tolerance errors %s"
-          % (kind, bad, total, worst))
-    assert bad <= 0.005 * total, (bad, total, worst)
+    r = _step_parity(env_id, kind, n=256, steps=60, seed=11)
+    u = ~r["flag"]
+    print("single-step parity %s: %d env-steps, %.2f %% flagged (decision within 1e-5 of a threshold, or fp32-vs-fp64 oracle "
+          "disagreement > 2.5e-5); unflagged: max |obs| %.2e, > 1e-4: %d, max state rel %.2e, max |rew| %.2e; integer mismatches "
+          "(all on flagged steps): %d" % (kind, u.size, 100 * r["flag"].mean(), r["e_obs"][u].max(), (r["e_obs"][u] > 1e-4).sum(),
+                                          r["e_state"][u].max(), r["e_rew"][u].max(), (~r["ints"]).sum()))
+    assert r["flag"].mean() < 0.05
+    assert r["ints"][u].all(), "integer / done mismatch on an unflagged env-step"
+    assert r["e_obs"][u].max() < 5e-4 and (r["e_obs"][u] > 1e-4).mean() < 5e-4
+    assert r["e_rew"][u].max() < 1e-3 and r["e_state"][u].max() < 2.5e-3
+    assert np.quantile(r["e_obs"], 0.99) < 1e-4          # all env-steps, flagged ones included
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_single_step_parity_on_curriculum_terrain(env_id, kind):
+    """Same rule on tilted / turned stones (curriculum 5, grid drawn stones in play after the first resets)."""
+    r = _step_parity(env_id, kind, n=256, steps=40, seed=23, curriculum=5)
+    u = ~r["flag"]
+    assert r["flag"].mean() < 0.05 and r["ints"][u].all()
+    assert r["e_obs"][u].max() < 5e-4 and (r["e_obs"][u] > 1e-4).mean() < 5e-4
+    assert r["e_rew"][u].max() < 1e-3 and r["e_state"][u].max() < 2.5e-3
 
 
 def _stand_on_target(o, n_envs):

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-( cd $R && timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > $O/${tag}_pytest_gpu.log
+( cd $R && timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > $O/${tag}_pytest_gpu.log
 ( cd $R && python bench.py ) > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline > $O/${tag}_bench_under_rocprof.json 2>/dev/null
 cp $(ls /tmp/kt/*/*kernel_stats.csv | head -1) $O/${tag}_rocprofv3_kernel_stats.csv
@@ -16,10 +16,12 @@ for N in 4096 32768; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/hb/$C -- python $R/tools/hbm_traffic.py $N > /dev/null 2>&1
   done
-  python $R/tools/hbm_traffic_report.py /tmp/hb $N > $O/${tag}_hbm_traffic_$N.json
+  python $R/tools/hbm_traffic_report.py /tmp/hb $N step > $O/${tag}_hbm_traffic_$N.json
+  python $R/tools/hbm_traffic_report.py /tmp/hb $N rollout > $O/${tag}_hbm_traffic_rollout_$N.json
 done
-python $R/tools/pmc_profile.py 4096 $O/${tag}_pmc_4096.json > /dev/null
-python $R/tools/pmc_profile.py 32768 $O/${tag}_pmc_32768.json > /dev/null
+python $R/tools/pmc_profile.py 4096 $O/${tag}_pmc_4096.json rollout > /dev/null
+python $R/tools/pmc_profile.py 4096 $O/${tag}_pmc_step_4096.json step > /dev/null
+python $R/tools/pmc_profile.py 32768 $O/${tag}_pmc_32768.json rollout > /dev/null
 python $R/tools/scaling_n.py > $O/${tag}_scaling_envs.txt
 python $R/tools/contact_cost.py > $O/${tag}_regimes.txt
 ls -la $O | tail -20

@@ -6,6 +6,9 @@ import collections, csv, glob, json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N = sys.argv[1] if len(sys.argv) > 1 else "4096"
 OUT = sys.argv[2] if len(sys.argv) > 2 else None
+WHICH = sys.argv[3] if len(sys.argv) > 3 else "rollout"      # rollout: ss::rollout_kernel* (250 steps per launch); step: ss::step_kernel*
+PAT = "rollout_kernel" if WHICH == "rollout" else "step_kernel"
+STEPS_PER_LAUNCH = 250 if WHICH == "rollout" else 1
 GROUPS = [
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY",
     "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH",
@@ -23,13 +26,13 @@ for g in GROUPS:
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"]:
+            if PAT in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k] = sum(v) / len(v)
 waves = res.get("SQ_WAVES", 1.0) or 1.0
 per_wave = {k: round(v / waves, 1) for k, v in sorted(res.items())}
-summary = {"envs": int(N), "waves_per_launch": waves, "per_wave_per_launch": per_wave}
+summary = {"envs": int(N), "kernel": PAT, "steps_per_launch": STEPS_PER_LAUNCH, "waves_per_launch": waves, "per_wave_per_launch": per_wave}
 wc = per_wave.get("SQ_WAVE_CYCLES")
 if wc:
     summary["fractions_of_wave_cycles"] = {k: round(per_wave[k] / wc, 3) for k in
