@@ -1,18 +1,25 @@
-"""Multi-GPU sharding of the vectorised env: one process per GPU (torchrun), contiguous blocks of N/G envs per
-rank, rank-local state never moves.  The reference's only parallelism is one OS process per env behind pipes
-(common/envs_utils.py:519-538); here the single exchange per step is an all-gather (RCCL over xGMI when the
-backend is "nccl") of the packed [N/G, 62] = [obs | rew | done] block so every rank holds the (N,60) obs and (N,)
-rew / done the single-learner loop of playground/train.py:363-469 expects.  Actions flow the other way by slicing.
-Global env ids (env_id_offset = rank * N/G) key the RNG streams, so results do not depend on G.
+"""Multi-GPU sharding of the vectorised env: one process per GPU (torchrun or steppingstone_amd.launch), contiguous
+blocks of N/G envs per rank, rank-local state never moves.  The reference's only parallelism is one OS process per env
+behind pipes (common/envs_utils.py:519-538); here the single exchange per step is an all-gather (RCCL over xGMI when the
+backend is "nccl") so every rank holds the (N,60) obs and (N,) rew / done the single-learner loop of
+playground/train.py:363-469 expects.  Actions flow the other way by slicing.  Global env ids (env_id_offset =
+rank * N/G) key the RNG streams, so results do not depend on G.
+
+Two exchange layouts, both written directly by the step kernel (no pack / copy kernels):
+  * rollout_random (benchmark, BASELINE configs[3]): the packed [N/G, 62] f32 block obs | rew | done;
+  * step (learner-facing): one flat buffer per rank = packed block + the [N/G, 5] info words (ep_ret, ep_len,
+    bad_transition, steps_reached, update_terrain) behind it, gathered in ONE collective, so the info dict is global
+    like obs / rew / done (what collect() of steppingstone_amd.ppo needs for its masks and episode statistics).
 """
 import os
 
 import torch
 import torch.distributed as dist
 
-from ._lib import ACT_DIM, OBS_DIM
+from ._lib import ACT_DIM, NCELL, OBS_DIM
 
 PACK = OBS_DIM + 2
+INFO = 5
 DEPTH = 8
 
 
@@ -27,7 +34,8 @@ class ShardedVecEnv:
         # SS_FORCE_COLLECTIVE=1 issues the all-gather even at world size 1 (exercises the RCCL path on a 1-GPU box)
         self._collective = self.world > 1 or (dist.is_initialized() and os.environ.get("SS_FORCE_COLLECTIVE") == "1")
         self.n_local = int(local_env.num_envs)
-        if self._collective and torch.device(local_env.device).type == "cuda":
+        self.device = torch.device(local_env.device)
+        if self._collective and self.device.type == "cuda":
             # HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) round robin, and the first
             # stream taken from PyTorch's pool lands on the default stream's queue: if that is RCCL's stream, the
             # all-gather cannot run under the step kernel (measured +26 us per 0.11 ms step instead of +9 us,
@@ -39,7 +47,7 @@ class ShardedVecEnv:
         self.num_envs = self.n_local * self.world
         self.observation_space = getattr(local_env, "observation_space", None)
         self.action_space = getattr(local_env, "action_space", None)
-        dev = local_env.device
+        dev = self.device
         # ring of DEPTH buffers: the all-gather of step t runs under the kernels of steps t+1.. and the launch stream
         # waits on the collectives once per DEPTH steps, as one batch.  Measured on one rank with the collective forced:
         # a cross-stream wait before every kernel (any depth) costs +26 us per 0.11 ms step, batched waits every 8
@@ -47,6 +55,12 @@ class ShardedVecEnv:
         self._packed = [torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         self._gathered = [torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         self._work = [None] * DEPTH
+        # learner-facing step: packed block and info words in one flat buffer, one collective
+        self._chunk = self.n_local * (PACK + INFO)
+        self._flat = torch.zeros(self._chunk, dtype=torch.float32, device=dev)
+        self._flat_all = torch.zeros(self._chunk * self.world, dtype=torch.float32, device=dev)
+        self._flat_packed = self._flat[:self.n_local * PACK].view(self.n_local, PACK)
+        self._flat_info = self._flat[self.n_local * PACK:].view(torch.int32).view(self.n_local, INFO)
 
     # -- helpers
     def local_slice(self):
@@ -69,24 +83,41 @@ class ShardedVecEnv:
         self._work[slot] = w if async_op else None
         return self._gathered[slot]
 
+    def _gather_flat(self):
+        """One collective for packed block + info words; returns global (packed [N,62], info [N,5] int32)."""
+        if not self._collective:
+            return self._flat_packed, self._flat_info
+        dist.all_gather_into_tensor(self._flat_all, self._flat, group=self.group)
+        per_rank = self._flat_all.view(self.world, self._chunk)
+        packed = per_rank[:, :self.n_local * PACK].reshape(self.num_envs, PACK)
+        info = per_rank[:, self.n_local * PACK:].reshape(self.num_envs * INFO).view(torch.int32).view(self.num_envs, INFO)
+        return packed, info
+
+    @staticmethod
+    def _info_dict(info):
+        fl = info[:, 0:2].view(torch.float32)
+        return {"ep_ret": fl[:, 0], "ep_len": fl[:, 1], "bad_transition": info[:, 2], "steps_reached": info[:, 3],
+                "update_terrain": info[:, 4]}
+
     # -- VecEnv protocol on GLOBAL arrays
     def reset(self):
         obs = self.local.reset()
-        self._wait(0)
-        self._packed[0].zero_()
-        self._packed[0][:, :OBS_DIM] = obs
-        return self._split(self._gather_packed(0))[0]
+        self._flat.zero_()
+        self._flat_packed[:, :OBS_DIM] = obs
+        packed, _ = self._gather_flat()
+        return self._split(packed)[0]
 
     def step(self, actions):
-        """actions: (N,21) global (every rank passes the same tensor) or (N/G,21) already local."""
+        """actions: (N,21) global (every rank passes the same tensor) or (N/G,21) already local.  Returns GLOBAL obs
+        (N,60), rew (N,), done (N,) and a GLOBAL info dict of (N,) tensors."""
         a = actions
         if a.shape[0] == self.num_envs and self.world > 1:
             a = a[self.local_slice()]
         assert a.shape == (self.n_local, ACT_DIM)
-        self._wait(0)
-        self.local.step_packed(self._packed[0], actions=a)
-        gobs, grew, gdone = self._split(self._gather_packed(0))
-        return gobs, grew, gdone, self.local._info_tensors()   # info stays rank-local (episode stats reduce separately)
+        self.local.step_packed(self._flat_packed, actions=a, info=self._flat_info)
+        packed, info = self._gather_flat()
+        gobs, grew, gdone = self._split(packed)
+        return gobs, grew, gdone, self._info_dict(info)
 
     def rollout_random(self, num_steps, t0=0, gather=True):
         """Benchmark path: each of num_steps steps = one local kernel launch writing the packed block + (when
@@ -105,6 +136,7 @@ class ShardedVecEnv:
         g = self._gathered[slot] if (gather and self._collective) else self._packed[slot]
         return self._split(g)
 
+    # -- hooks: every rank applies the same value (broadcast-free)
     def update_curriculum(self, c):
         self.local.update_curriculum(c)
 
@@ -112,14 +144,31 @@ class ShardedVecEnv:
         self.local.update_specialist(c)
 
     def update_sample_prob(self, probs):
-        import numpy as np
-        probs = np.asarray(probs)
-        if probs.ndim == 3 and probs.shape[0] == self.num_envs and self.world > 1:
+        """(11,11) shared grid, or (N,11,11) GLOBAL per-env grids (this rank takes its block)."""
+        if hasattr(probs, "shape") and len(probs.shape) == 3 and probs.shape[0] == self.num_envs and self.world > 1:
             probs = probs[self.local_slice()]
         self.local.update_sample_prob(probs)
 
     def set_mirror(self, m):
         self.local.set_mirror(m)
+
+    def set_env_params(self, params):
+        self.local.set_env_params(params)
+
+    def set_robot_params(self, params):
+        self.local.set_robot_params(params)
+
+    def get_mirror_indices(self):
+        return self.local.get_mirror_indices()
+
+    def create_temp_states(self):
+        """(N,121,60): every rank's block gathered (119 MB per 4096 envs: the sampler calls this on small eval batches)."""
+        loc = self.local.create_temp_states()
+        if not self._collective:
+            return loc
+        out = torch.empty((self.num_envs, NCELL, OBS_DIM), dtype=loc.dtype, device=loc.device)
+        dist.all_gather_into_tensor(out, loc.contiguous(), group=self.group)
+        return out
 
     def close(self):
         self.local.close()

@@ -254,12 +254,14 @@ class SteppingStoneVecEnv:
         self.backend.rollout_random(num_steps, t0, self._obs, self._rew, self._done, self._info, steps_per_launch)
         return self._obs, self._rew, self._done
 
-    def step_packed(self, packed, actions=None, t=0):
+    def step_packed(self, packed, actions=None, t=0, info=None):
         """One step written into the caller's [N,62] buffer (obs | rew | done): the block ShardedVecEnv all-gathers.
-        actions=None draws them from the benchmark Philox stream at index t."""
+        actions=None draws them from the benchmark Philox stream at index t.  info: optional caller-owned [N,5] int32
+        buffer for the per-env step report (default: this env's own)."""
         if actions is not None:
             self._act.copy_(actions.reshape(self.num_envs, ACT_DIM))
-        self.backend.step_packed(self._act if actions is not None else None, actions is None, t, packed, self._info)
+        self.backend.step_packed(self._act if actions is not None else None, actions is None, t, packed,
+                                 self._info if info is None else info)
         return packed
 
     def random_actions(self, t):

@@ -199,7 +199,8 @@ class PPO:
 
     def update(self, roll):
         adv = roll.returns[:-1] - roll.value_preds[:-1]
-        adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+        mean, std = _global_mean_std(adv)          # over ALL ranks' transitions (= the reference's statistics on one rank)
+        adv = (adv - mean) / (std + 1e-5)
         T, N = roll.rewards.shape[:2]
         flat = lambda t: t.reshape(T * N, -1)   # noqa: E731
         data = (flat(roll.obs[:-1]), flat(roll.actions), flat(roll.value_preds[:-1]), flat(roll.returns[:-1]),
@@ -218,6 +219,65 @@ class PPO:
                     stats += torch.stack(self._gathered_step(data, idx))
                 count += 1
         return (stats / max(count, 1)).tolist()
+
+
+def _dist_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _global_mean_std(x):
+    """mean and unbiased std of x over every rank's elements (algorithms/ppo.py:42-43 computes them on the single
+    process's whole batch; a data-parallel learner must use the same global statistics)."""
+    if _dist_world() == 1:
+        return x.mean(), x.std()
+    import torch.distributed as dist
+    x64 = x.double()
+    s = torch.stack([x64.sum(), (x64 * x64).sum(), torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
+    dist.all_reduce(s)
+    n = s[2]
+    mean = s[0] / n
+    var = (s[1] - n * mean * mean) / (n - 1)
+    return mean.to(x.dtype), var.clamp_min(0).sqrt().to(x.dtype)
+
+
+class EpisodeRing:
+    """The reference's `episode_rewards = deque(maxlen=num_processes)` (playground/train.py:193,454-456) as a device
+    ring buffer written with capturable tensor ops only (no host sync, no data-dependent shapes): finished episodes'
+    returns go to consecutive slots, everything else to a dump slot.  Eager and hipGraph rollouts therefore gate the
+    curriculum on the SAME statistic (mean of the last `size` episode returns)."""
+
+    def __init__(self, size, device):
+        self.size = int(size)
+        self.buf = torch.zeros(self.size + 1, device=device)          # [size] = dump slot
+        self.ptr = torch.zeros((), dtype=torch.long, device=device)
+        self.count = torch.zeros((), dtype=torch.long, device=device)
+
+    def push(self, ep_ret, done):
+        d = done.reshape(-1).to(torch.bool)
+        k = torch.cumsum(d.to(torch.long), 0) - 1
+        idx = torch.where(d, (self.ptr + k) % self.size, torch.full_like(k, self.size))
+        self.buf.scatter_(0, idx, torch.where(d, ep_ret.reshape(-1).to(self.buf.dtype), self.buf[self.size].expand_as(k)))
+        nd = d.sum()
+        self.ptr.copy_((self.ptr + nd) % self.size)
+        self.count.copy_(torch.clamp(self.count + nd, max=self.size))
+
+    def values(self):
+        """Host copy of the stored returns (one synchronisation), oldest-agnostic order."""
+        c = int(self.count)
+        if c == 0:
+            return torch.empty(0)
+        b = self.buf[:self.size].cpu()
+        return b if c == self.size else b[:c]       # before the first wrap the filled slots are 0..count-1
+
+    def all_ranks_sum_count(self):
+        """(sum, count) over every rank's ring: the curriculum gate must be one decision for all ranks."""
+        v = torch.stack([self.buf[:self.size].sum().double(), self.count.double()])
+        if _dist_world() > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v)
+        s, c = v.tolist()
+        return s, int(c)
 
 
 class Rollouts:
@@ -249,18 +309,21 @@ class Rollouts:
             self.value_preds[-1] = next_value
 
 
-def collect(envs, ac, roll, num_steps, ep_returns=None, ep_stats=None):
-    """The rollout loop of playground/train.py:363-469 with tensorised bookkeeping.  `envs` returns device tensors
-    (SteppingStoneVecEnv(return_numpy=False) or ShardedVecEnv).  Finished episodes are reported either through
-    ep_stats, a device tensor [2] accumulating (sum of returns, count) with no host synchronisation (the form a
-    hipGraph can capture), or appended to the list ep_returns (one host sync per step)."""
+def collect(envs, ac, roll, num_steps, ep_returns=None, ep_stats=None, ring=None, deterministic=False):
+    """The rollout loop of playground/train.py:363-469 with tensorised bookkeeping.  `envs` returns device tensors with
+    GLOBAL shapes equal to roll's env dimension (SteppingStoneVecEnv(return_numpy=False), or ShardedVecEnv whose step()
+    all-gathers obs / rew / done AND the info words).  Finished episodes are reported through `ring` (EpisodeRing, the
+    reference's deque; capturable), and optionally through ep_stats, a device tensor [2] accumulating (sum of returns,
+    count), or the host list ep_returns (one host sync per step)."""
     for _ in range(num_steps):
         with torch.no_grad():
-            value, action, logp = ac.act(roll.obs[roll.step])
+            value, action, logp = ac.act(roll.obs[roll.step], deterministic=deterministic)
         obs, rew, done, info = envs.step(action)
         d = done.to(torch.float32).unsqueeze(1)
         mask = 1.0 - d
         bad_mask = 1.0 - info["bad_transition"].to(torch.float32).unsqueeze(1)
+        if ring is not None:
+            ring.push(info["ep_ret"], done)
         if ep_stats is not None:
             ep_stats[0] += (info["ep_ret"] * d[:, 0]).sum()
             ep_stats[1] += d.sum()
@@ -274,8 +337,8 @@ class GraphedCollector:
     steps: ~50 launches per step) and replayed per update.  The rollout storage, the env's I/O buffers and the
     episode accumulators are static, and every call starts at roll.step == 0, so all addresses are replay-stable."""
 
-    def __init__(self, envs, ac, roll, num_steps):
-        self.envs, self.ac, self.roll, self.num_steps = envs, ac, roll, num_steps
+    def __init__(self, envs, ac, roll, num_steps, ring=None):
+        self.envs, self.ac, self.roll, self.num_steps, self.ring = envs, ac, roll, num_steps, ring
         self.ep_stats = torch.zeros(2, device=roll.obs.device)
         self.graph, self.warm = None, 0
 
@@ -288,23 +351,27 @@ class GraphedCollector:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats)
+                    collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats, ring=self.ring)
                 torch.cuda.current_stream().wait_stream(side)
                 return self.ep_stats
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats)
+                collect(self.envs, self.ac, self.roll, self.num_steps, ep_stats=self.ep_stats, ring=self.ring)
             self.graph = g
         self.graph.replay()
         return self.ep_stats
 
 
-def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_threshold=0.85, events=5, max_steps=400):
+def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_threshold=0.85, events=5, max_steps=400,
+                               as_tensor=False):
     """Adaptive / threshold curriculum sampler (playground/train.py:229-272, 320-361), batched: the evaluation envs
-    are rolled with the deterministic policy; every env that advances to a new target contributes the critic-ensemble
-    value of its 121 hypothetical next stones (create_temp_states); after `events` such contributions the summed
-    11x11 metric, normalised by its absolute maximum, becomes softmax(-10 |m - threshold|) ("threshold") or
-    softmax(-10 m) ("adaptive").  Returns an (11,11) float64 numpy grid for update_sample_prob."""
+    are rolled with the deterministic policy (auto-reset on, like the reference's `if done: reset`); every env that
+    advances to a new target contributes the critic-ensemble mean value of its 121 hypothetical next stones
+    (create_temp_states); the first `events` such contributions (env order within a step) are summed, the sum is
+    normalised by its absolute maximum and becomes softmax(-10 |m - threshold|) ("threshold", train.py:262) or
+    softmax(-10 m) ("adaptive", train.py:354).  Returns the (11,11) grid as float64 numpy (what update_sample_prob gets in
+    the reference) or, as_tensor=True, as a float32 tensor on the env's device (stream-ordered hook, no host copy);
+    None if fewer than one event happened within max_steps."""
     dev = eval_envs.device
     obs = eval_envs.reset()
     total = torch.zeros(121, device=dev)
@@ -315,59 +382,151 @@ def sampling_probs_from_values(ac, eval_envs, mode="threshold", curriculum_thres
         obs, _, _, info = eval_envs.step(action)
         hit = info["update_terrain"] > 0
         if bool(hit.any()):
-            temp = eval_envs.create_temp_states()[hit]                      # [k,121,60]
+            temp = eval_envs.create_temp_states()[hit][:events - seen]      # [k,121,60], at most the missing events
             with torch.no_grad():
                 v = ac.get_ensemble_values(temp.reshape(-1, temp.shape[-1])).mean(dim=-1)
             total += v.view(-1, 121).sum(dim=0)
-            seen += int(hit.sum())
+            seen += temp.shape[0]
             if seen >= events:
                 break
     if seen == 0:
         return None
     m = total / total.abs().max()
     logits = -10.0 * (m - curriculum_threshold).abs() if mode == "threshold" else -10.0 * m
-    return torch.softmax(logits, dim=0).view(11, 11).double().cpu().numpy()
+    p = torch.softmax(logits, dim=0).view(11, 11)
+    return p if as_tensor else p.double().cpu().numpy()
+
+
+def evaluate(test_envs, ac, max_steps):
+    """The deterministic test loop of playground/train.py:472-500: reset the test envs, run the deterministic policy for
+    max_steps steps (auto-reset on), collect the returns of the episodes that finish.  Returns a 1-D CPU tensor."""
+    obs = test_envs.reset()
+    rets = []
+    for _ in range(max_steps):
+        with torch.no_grad():
+            _, action, _ = ac.act(obs, deterministic=True)
+        obs, _, done, info = test_envs.step(action)
+        rets.append(torch.where(done, info["ep_ret"], torch.full_like(info["ep_ret"], float("nan"))))
+    r = torch.stack(rets).reshape(-1).cpu()
+    return r[~torch.isnan(r)]
+
+
+def save_checkpoint(ac, path, **meta):
+    """{env}_latest.pt / {env}_best.pt / {env}_{frames}.pt (playground/train.py:523-562).  The reference pickles the
+    whole module (its class source travels with the file); here the file holds the CPU state_dict plus the few numbers
+    needed to rebuild the module -- torch.load(path)["state_dict"] -> ActorCritic(...).load_state_dict."""
+    sd = {k: v.detach().cpu() for k, v in ac.state_dict().items()}
+    torch.save({"state_dict": sd, "num_ensembles": len(ac.critics), "state_dim": ac.actor.state_dim,
+                "action_dim": ac.actor.action_dim, **meta}, path)
+
+
+def load_checkpoint(path, device="cpu"):
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ac = ActorCritic(ck["state_dim"], ck["action_dim"], num_ensembles=ck["num_ensembles"])
+    ac.load_state_dict(ck["state_dict"])
+    return ac.to(device), ck
 
 
 def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curriculum=True, use_mirror=False, lr=3e-4,
-          gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto"):
-    """Fixed-order-curriculum PPO (playground/train.py:115-118,211-222,503-521).  Returns the list of per-update stats.
-    use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs, and the episode
-    statistics stay on the device (mean return of the episodes finished during the update, carried over when none
-    finished) instead of the reference's host-side deque."""
+          gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto",
+          sampling="none", eval_envs=None, curriculum_threshold=0.85, uniform_every=500000,
+          test_envs=None, test_interval=1, logger=None, save_dir="", save_every=1e7, env_name="env",
+          use_specialist=False):
+    """The training loop of playground/train.py:211-578 on device tensors.  Returns (actor_critic, per-update stats).
+
+      use_curriculum   fixed-order curriculum: level += 1 while mean(recent episode returns) > 1000 (train.py:115-118,503-506)
+      use_specialist   same gate, ring windows + a `{env}_specialist_{k}.pt` file per level (train.py:119-122,538-545)
+      sampling         "threshold" (train.py:123-133,229-272,460-469) / "adaptive" (train.py:134-137,320-361): the grid of
+                       the next-next stone is re-estimated EVERY update from the critic ensemble on `eval_envs` (a small
+                       batch at curriculum 0; the reference uses one env); "threshold" starts with one uniform update
+                       (curriculum 5) and repeats it every `uniform_every` updates
+      test_envs        deterministic evaluation every `test_interval` updates for max_episode_steps steps (train.py:472-500;
+                       the reference does it every update)
+      logger           ConsoleCSVLogger-compatible object (steppingstone_amd.csv_logger): log_epoch(dict) per update
+      save_dir         `{env}_latest.pt` every update, `{env}_{frames}.pt` every save_every frames, `{env}_best.pt` on a new
+                       best mean return (train.py:523-562)
+    use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs.  Episode returns go
+    through a device ring of the last num_envs episodes in both modes (EpisodeRing = the reference's deque).
+    Under torch.distributed (one rank per GPU) every rank passes its LOCAL envs: gradients and the advantage statistics
+    are all-reduced, parameters start identical (broadcast from rank 0), exploration noise is seeded per rank, and the
+    curriculum gate uses the all-reduced episode statistics so that every rank takes the same decision."""
+    import os
     import torch.distributed as dist
-    torch.manual_seed(seed)
-    dev = envs.device if hasattr(envs, "device") else envs.local.device
-    dev = torch.device(dev)
+    dev = torch.device(envs.device if hasattr(envs, "device") else envs.local.device)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    world = dist.get_world_size() if multi else 1
     if use_graph == "auto":
         use_graph = dev.type == "cuda" and not multi
+    torch.manual_seed(seed)
     ac = ActorCritic(num_ensembles=num_ensembles).to(dev)
+    if multi:
+        for p_ in ac.parameters():
+            dist.broadcast(p_.data, src=0)
+        torch.manual_seed(seed + 7919 * rank)            # decorrelate exploration noise / minibatch order across ranks
     mirror = envs.get_mirror_indices() if use_mirror and hasattr(envs, "get_mirror_indices") else None
     agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=use_graph)
     n = envs.num_envs
     roll = Rollouts(num_steps, n, dev)
-    curriculum = 0
+    ring = EpisodeRing(n, dev)
+    curriculum = specialist = 0
     if use_curriculum:
         envs.update_curriculum(curriculum)
+    if use_specialist:
+        envs.update_specialist(specialist)
+    uniform_sampling, uniform_counter = True, 1            # train.py:124-128
+    if sampling != "none":
+        assert eval_envs is not None, "adaptive / threshold sampling needs eval_envs"
+        eval_envs.update_curriculum(0)                    # train.py:131,137
     roll.obs[0].copy_(envs.reset())
-    collector = GraphedCollector(envs, ac, roll, num_steps) if use_graph else None
-    recent, history, start = [], [], time.time()
-    mean_ret = float("nan")
+    collector = GraphedCollector(envs, ac, roll, num_steps, ring=ring) if use_graph else None
+    history, start = [], time.time()
+    test_rets = torch.empty(0)
+    next_checkpoint, max_ep_reward = save_every, float("-inf")
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
     for j in range(num_updates):
         agent.set_lr(harness.exponential_decay(j, 0.99, lr, 3e-5))
+        # -- sampling grid of this update (train.py:229-272, 320-361)
+        grid_updated = False
+        if sampling == "threshold" and uniform_sampling:
+            envs.update_curriculum(5)
+        elif sampling in ("threshold", "adaptive"):
+            g = None
+            if rank == 0:
+                g = sampling_probs_from_values(ac, eval_envs, mode=sampling, curriculum_threshold=curriculum_threshold,
+                                               as_tensor=dev.type == "cuda")
+            if multi:                                     # one grid for the whole job: rank 0's
+                gt, ok = torch.zeros((11, 11), device=dev), torch.zeros(1, device=dev)
+                if g is not None:
+                    gt.copy_(torch.as_tensor(g, dtype=torch.float32))
+                    ok.fill_(1)
+                dist.broadcast(ok, src=0)
+                dist.broadcast(gt, src=0)
+                g = (gt if dev.type == "cuda" else gt.double().numpy()) if bool(ok.item()) else None
+            if g is not None:
+                envs.update_sample_prob(g)
+                grid_updated = True
+        # -- rollout
         if collector is not None:
-            ssum, cnt = collector().tolist()               # the one host sync of the rollout
-            if cnt > 0:
-                mean_ret = ssum / cnt
-            have = not math.isnan(mean_ret)
+            collector()
         else:
-            ep = []
-            collect(envs, ac, roll, num_steps, ep)
-            recent = (recent + ep)[-50:]
-            mean_ret = float(torch.cat(recent).mean()) if recent else float("nan")
-            have = bool(recent)
-        if use_curriculum and have and mean_ret > 1000 and curriculum <= 4:
+            collect(envs, ac, roll, num_steps, ring=ring)
+        if sampling == "threshold":                       # train.py:460-469
+            uniform_sampling = (uniform_counter % uniform_every == 0)
+            uniform_counter = 0 if uniform_sampling else uniform_counter
+            uniform_counter += 1
+            if uniform_sampling:
+                envs.update_curriculum(5)
+        # -- deterministic test episodes (train.py:472-500)
+        if test_envs is not None and test_interval and j % test_interval == 0:
+            r = evaluate(test_envs, ac, getattr(test_envs, "_max_episode_steps", 1000))
+            if r.numel():
+                test_rets = torch.cat([test_rets, r])[-test_envs.num_envs:]      # deque(maxlen=num_tests)
+        # -- curriculum gate on the recent-episode mean, one decision for all ranks
+        ssum, cnt = ring.all_ranks_sum_count()            # the one host sync of the rollout
+        mean_ret = ssum / cnt if cnt else float("nan")
+        if use_curriculum and cnt and mean_ret > 1000 and curriculum <= 4:
             curriculum += 1
             envs.update_curriculum(curriculum)
         with torch.no_grad():
@@ -375,10 +534,32 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
         roll.compute_returns(next_value, True, gamma, gae_lambda)
         vl, al, ent = agent.update(roll)
         roll.after_update()
-        frames = (j + 1) * num_steps * n
+        frames = (j + 1) * num_steps * n * world
+        # -- checkpoints (rank 0)
+        if save_dir and rank == 0:
+            if frames >= next_checkpoint or j == num_updates - 1:
+                name = "%s_%d.pt" % (env_name, int(next_checkpoint))
+                next_checkpoint += save_every
+            else:
+                name = "%s_latest.pt" % env_name
+            save_checkpoint(ac, os.path.join(save_dir, name), frames=frames, update=j + 1)
+            if cnt > 1 and mean_ret > max_ep_reward:
+                max_ep_reward = mean_ret
+                save_checkpoint(ac, os.path.join(save_dir, "%s_best.pt" % env_name), frames=frames, update=j + 1, mean_rew=mean_ret)
+        if use_specialist and cnt and mean_ret > 1000 and specialist <= 4:
+            if save_dir and rank == 0:
+                save_checkpoint(ac, os.path.join(save_dir, "%s_specialist_%d.pt" % (env_name, specialist)), frames=frames)
+            specialist += 1
+            envs.update_specialist(specialist)
         stats = {"iter": j + 1, "total_num_steps": frames, "fps": int(frames / (time.time() - start)), "entropy": ent,
-                 "value_loss": vl, "action_loss": al, "mean_rew": mean_ret, "curriculum": curriculum}
+                 "value_loss": vl, "action_loss": al, "mean_rew": mean_ret, "curriculum": curriculum,
+                 "grid_updated": grid_updated}
         history.append(stats)
+        if logger is not None and rank == 0 and cnt > 1:      # train.py:564: only once episodes have finished
+            vals = ring.values()
+            logger.log_epoch({"iter": j + 1, "total_num_steps": frames, "fps": stats["fps"], "entropy": ent,
+                              "value_loss": vl, "action_loss": al, "stats": {"rew": vals.numpy()},
+                              "test_stats": {"rew": (test_rets if test_rets.numel() else torch.full((1,), float("nan"))).numpy()}})
         if log:
             log(stats)
     return ac, history

@@ -13,11 +13,11 @@ from steppingstone_amd.envs import SteppingStoneVecEnv
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "harness_golden.npz"))
 
 
-@pytest.mark.parametrize("tag,use_gae", [("gae", True), ("ret", False)])
-def test_returns_match_reference(tag, use_gae):
-    t = lambda k: torch.from_numpy(G[tag + "_" + k])  # noqa: E731
+def check_returns(device, tag, use_gae):
+    """algorithms/storage.py:59-82 on the golden batch (shared with the -m gpu run, tests/test_gpu_golden.py)."""
+    t = lambda k: torch.from_numpy(G[tag + "_" + k]).to(device)  # noqa: E731
     vals = t("values")
-    ret = harness.compute_returns(t("rewards"), vals, t("masks"), t("bad"), vals[-1].clone(), use_gae, 0.99, 0.95)
+    ret = harness.compute_returns(t("rewards"), vals, t("masks"), t("bad"), vals[-1].clone(), use_gae, 0.99, 0.95).cpu()
     ref = G[tag + "_returns"]
     T = ref.shape[0] - 1
     assert np.allclose(ret.numpy()[:T], ref[:T], atol=1e-6)
@@ -25,19 +25,29 @@ def test_returns_match_reference(tag, use_gae):
         assert np.allclose(ret.numpy()[T], ref[T], atol=1e-6)
 
 
-def test_mirror_function_matches_reference():
-    obs, act = torch.from_numpy(G["mirror_obs_in"]), torch.from_numpy(G["mirror_act_in"])
+@pytest.mark.parametrize("tag,use_gae", [("gae", True), ("ret", False)])
+def test_returns_match_reference(tag, use_gae):
+    check_returns("cpu", tag, use_gae)
+
+
+def check_mirror(device):
+    """common/envs_utils.py:687-740 on the golden batch with this library's index lists."""
+    obs, act = torch.from_numpy(G["mirror_obs_in"]).to(device), torch.from_numpy(G["mirror_act_in"]).to(device)
     idx = _lib.mirror_indices()
     o2, a2 = harness.mirror_batch(obs, act, idx)
-    assert np.array_equal(o2.numpy(), G["mirror_obs_out"])
-    assert np.array_equal(a2.numpy(), G["mirror_act_out"])
-    z = torch.zeros(3, 1)
+    assert np.array_equal(o2.cpu().numpy(), G["mirror_obs_out"])
+    assert np.array_equal(a2.cpu().numpy(), G["mirror_act_out"])
+    z = torch.zeros(3, 1, device=device)
     res = harness.get_mirror_function(idx)((obs, z, act, z, z, z, z, z))
     assert len(res) == 8 and res[1].shape == (6, 1)
-    assert np.array_equal(res[0].numpy(), G["mirror_obs_out"]) and np.array_equal(res[2].numpy(), G["mirror_act_out"])
+    assert np.array_equal(res[0].cpu().numpy(), G["mirror_obs_out"]) and np.array_equal(res[2].cpu().numpy(), G["mirror_act_out"])
     # mirroring twice is the identity
     o4, a4 = harness.mirror_batch(o2[3:], a2[3:], idx)
-    assert np.array_equal(o4[3:].numpy(), obs.numpy()) and np.array_equal(a4[3:].numpy(), act.numpy())
+    assert np.array_equal(o4[3:].cpu().numpy(), obs.cpu().numpy()) and np.array_equal(a4[3:].cpu().numpy(), act.cpu().numpy())
+
+
+def test_mirror_function_matches_reference():
+    check_mirror("cpu")
 
 
 def test_decay_schedules_match_reference():

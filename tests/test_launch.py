@@ -1,0 +1,41 @@
+"""`python bench.py --gpus N` / `python -m steppingstone_amd.train --gpus N` start their own N ranks when no launcher
+did (the reference's make_vec_envs forks its own workers, common/envs_utils.py:519-538).
+CPU only: --dry-launch makes every rank report RANK / WORLD_SIZE and exit before touching a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return e
+
+
+def test_bench_self_launches_two_ranks():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], cwd=ROOT, env=_env(),
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in rows) == [0, 1] and all(r["world_size"] == 2 for r in rows)
+    assert all(r["master"].startswith("127.0.0.1:") for r in rows)
+
+
+def test_bench_under_an_external_launcher_does_not_relaunch():
+    from steppingstone_amd import launch
+    cmd = launch.launcher_command(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"])
+    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 2                                   # two ranks, each printed once: no nested launch
+
+
+def test_rank_count_mismatch_is_an_error():
+    e = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], cwd=ROOT, env=e,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "launcher started 3 ranks" in (out.stderr + out.stdout)

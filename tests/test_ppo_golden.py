@@ -28,25 +28,37 @@ def load_reference_weights(ac, prefix):
     ac.load_state_dict(sd, strict=True)
 
 
-def test_one_ppo_update_matches_reference():
+def check_one_ppo_update(device, **tol):
+    """algorithms/ppo.py:40-108 on the golden batch: three losses and every weight after one Adam step.  Shared by the
+    CPU test below and the -m gpu test (tests/test_gpu_golden.py runs it on cuda, eagerly and through the hipGraph step)."""
+    device = torch.device(device)
     ac = ppo.ActorCritic(num_ensembles=2)
     load_reference_weights(ac, "ppo_w0/")
+    ac = ac.to(device)
     T, N = G["ppo_act"].shape[:2]
-    t = lambda k: torch.from_numpy(G["ppo_" + k])  # noqa: E731
-    roll = ppo.Rollouts(T, N, torch.device("cpu"))
+    t = lambda k: torch.from_numpy(G["ppo_" + k]).to(device)  # noqa: E731
+    roll = ppo.Rollouts(T, N, device)
     roll.obs.copy_(t("obs")); roll.actions.copy_(t("act")); roll.logp.copy_(t("old_logp"))
     roll.value_preds.copy_(t("vpred")); roll.returns.copy_(t("returns"))
-    agent = ppo.PPO(ac, clip_param=0.2, ppo_epoch=1, mini_batch_size=T * N, lr=3e-4, eps=1e-5, max_grad_norm=2.0)
+    agent = ppo.PPO(ac, clip_param=0.2, ppo_epoch=1, mini_batch_size=T * N, lr=3e-4, eps=1e-5, max_grad_norm=2.0,
+                    use_graph=tol.get("use_graph", False))
+    if tol.get("use_graph"):
+        agent._warm = 3                                   # capture on the very first (and only) minibatch step
     vl, al, ent = agent.update(roll)
-    assert np.allclose([vl, al, ent], G["ppo_losses"], rtol=2e-5, atol=2e-6), ([vl, al, ent], G["ppo_losses"])
+    assert np.allclose([vl, al, ent], G["ppo_losses"], rtol=tol.get("loss_rtol", 2e-5), atol=tol.get("loss_atol", 2e-6)), \
+        ([vl, al, ent], G["ppo_losses"])
     ref = ppo.ActorCritic(num_ensembles=2)
     load_reference_weights(ref, "ppo_w1/")
     for (name, p), (_, q) in zip(ac.state_dict().items(), ref.state_dict().items()):
-        assert torch.allclose(p, q, rtol=1e-4, atol=2e-6), name
+        assert torch.allclose(p.cpu(), q, rtol=tol.get("w_rtol", 1e-4), atol=tol.get("w_atol", 2e-6)), name
     # the step moved the weights at all
     moved = ppo.ActorCritic(num_ensembles=2)
     load_reference_weights(moved, "ppo_w0/")
-    assert (moved.actor.fc1.weight - ac.actor.fc1.weight).abs().max() > 1e-5
+    assert (moved.actor.fc1.weight - ac.actor.fc1.weight.cpu()).abs().max() > 1e-5
+
+
+def test_one_ppo_update_matches_reference():
+    check_one_ppo_update("cpu")
 
 
 def test_actor_critic_shapes_and_logp():
