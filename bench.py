@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Mike / capacity side measurements")
     ap.add_argument("--no-gather", action="store_true", help="N>1: time only the collective-free rollout")
+    ap.add_argument("--no-peer-store", action="store_true", help="N>1: skip the peer-store side measurement")
     ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
     args = ap.parse_args()
 
@@ -290,16 +291,33 @@ def main():
             el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
             side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
             t_next += K
+            if not args.no_peer_store:
+                # the same exchange written by the step kernel itself into every peer's gather buffer (no collective in
+                # the data path; steppingstone_amd/peer.py).  A side row: a failure here never touches the headline value.
+                try:
+                    penv = ShardedVecEnv(local, peer_gather=True)
+                    penv.rollout_random(min(W, 50) or 8, t0=t_next, gather=True)
+                    el3, _ = timed(lambda: penv.rollout_random(K, t0=t_next + 50, gather=True))
+                    err = penv._peer.error() if penv._peer is not None else -1
+                    side["peer_store"] = {"ms_per_step": 1e3 * el3 / K, "wait_timeouts": err,
+                                          "note": "same K steps, packed block stored by the step kernel into every peer's "
+                                                  "gather buffer over xGMI + flag words instead of the RCCL all-gather"}
+                    penv._peer.close(); penv._peer = None
+                except Exception as exc:
+                    side["peer_store"] = {"ms_per_step": None, "error": repr(exc)[:300]}
+                t_next += K + 50
         _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
         kernel_ms_per_step = ev1 / K                       # back-to-back launches on one stream: sum of durations
 
-    t = torch.tensor([elapsed] + [side.get("no_gather", {}).get("ms_per_step", 0.0)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, side.get("no_gather", {}).get("ms_per_step", 0.0),
+                      side.get("peer_store", {}).get("ms_per_step") or 0.0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0].item())
-    if "no_gather" in side:
-        side["no_gather"]["ms_per_step"] = float(t[1].item())
-        side["no_gather"]["value"] = n_local * world / (side["no_gather"]["ms_per_step"] * 1e-3)
+    for i, key in ((1, "no_gather"), (2, "peer_store")):
+        if key in side and side[key].get("ms_per_step"):
+            side[key]["ms_per_step"] = float(t[i].item())
+            side[key]["value"] = n_local * world / (side[key]["ms_per_step"] * 1e-3)
 
     if rank == 0:
         total_envs = n_local * world

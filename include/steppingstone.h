@@ -82,6 +82,28 @@ int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, 
  * common/envs_utils.py:550-558,608-620).  use_random_actions != 0: actions from the benchmark Philox stream at index t. */
 int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64_t t, float* packed, ss_info* info,
                    void* stream);
+/* Peer-store all-gather: the multi-GPU exchange of SURVEY.md 8e WITHOUT a collective in the data path.  Every rank owns
+ * a gather buffer [G * N_local, 62] f32 and a flag array [G] u32 in fine-grained device memory (ss_peer_alloc; shared
+ * with the other ranks' processes through ss_peer_ipc_handle / ss_peer_ipc_open, 64-byte handles), one pair per ring
+ * slot.  ss_peer_connect gives the handle the gather-buffer and flag-array pointers of all G ranks as seen from THIS
+ * process (index = slot * G + rank; own entries included).
+ * ss_step_packed_peers is ss_step_packed whose kernel additionally stores its rows straight into every peer's gather
+ * buffer (xGMI peer-to-peer stores) and, from the last workgroup, publishes step_id in flag[rank] of every peer.
+ * ss_peer_wait enqueues a one-wavefront kernel that returns once all G peers have published step_id (or later) here:
+ * work enqueued behind it may read this rank's gather buffer.  step_id must increase from launch to launch; a buffer
+ * may be overwritten only after every peer has consumed it (use >= 2 buffers in turn).  ss_peer_error: non-zero if a
+ * wait timed out.  (packed may be NULL here: the gather buffer already holds this rank's own rows.) */
+int ss_peer_alloc(void** out, uint64_t bytes);
+int ss_peer_free(void* ptr);
+int ss_peer_ipc_handle(void* ptr, void* handle64);
+int ss_peer_ipc_open(const void* handle64, void** out);
+int ss_peer_ipc_close(void* ptr);
+int ss_peer_connect(ss_env* env, int32_t count, int32_t rank, int32_t slots, float* const* gather_bufs,
+                    uint32_t* const* flag_bufs);          /* pointer tables [slots][count]; slots <= 4 buffers used in turn */
+int ss_step_packed_peers(ss_env* env, const float* act, int use_random_actions, uint64_t t, int32_t slot, uint32_t step_id,
+                         float* packed, ss_info* info, void* stream);
+int ss_peer_wait(ss_env* env, int32_t slot, uint32_t step_id, void* stream);
+int ss_peer_error(ss_env* env, uint32_t* out);
 /* Same action stream written to act [N,21] (parity tests / external policies). */
 int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream);
 

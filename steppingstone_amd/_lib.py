@@ -16,6 +16,8 @@ SYMBOLS = [
     "ss_set_curriculum", "ss_set_specialist", "ss_set_sample_prob", "ss_set_mirror", "ss_set_power", "ss_set_auto_reset",
     "ss_create_temp_states", "ss_get_mirror_indices", "ss_get_state", "ss_set_state", "ss_get_obs", "ss_num_envs",
     "ss_version", "ss_set_sample_prob_device", "ss_debug_calib_copy", "ss_debug_phase_cycles",
+    "ss_peer_alloc", "ss_peer_free", "ss_peer_ipc_handle", "ss_peer_ipc_open", "ss_peer_ipc_close", "ss_peer_connect",
+    "ss_step_packed_peers", "ss_peer_wait", "ss_peer_error",
 ]
 
 
@@ -50,6 +52,15 @@ def load():
     lib.ss_set_specialist.argtypes = [vp, i32]
     lib.ss_set_sample_prob.argtypes = [vp, vp, C.c_int]
     lib.ss_set_sample_prob_device.argtypes = [vp, vp, C.c_int, vp]
+    lib.ss_peer_alloc.argtypes = [C.POINTER(vp), u64]
+    lib.ss_peer_free.argtypes = [vp]
+    lib.ss_peer_ipc_handle.argtypes = [vp, vp]
+    lib.ss_peer_ipc_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.ss_peer_ipc_close.argtypes = [vp]
+    lib.ss_peer_connect.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.ss_step_packed_peers.argtypes = [vp, vp, C.c_int, u64, i32, C.c_uint32, vp, vp, vp]
+    lib.ss_peer_wait.argtypes = [vp, i32, C.c_uint32, vp]
+    lib.ss_peer_error.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.ss_debug_calib_copy.argtypes = [vp, vp, u64, vp]
     lib.ss_debug_phase_cycles.argtypes = [vp, vp, C.c_int]
     lib.ss_set_mirror.argtypes = [vp, i32]

@@ -13,6 +13,7 @@
 namespace {
 
 thread_local std::string g_err;
+constexpr int kMaxPeerSlots = 4;
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -40,6 +41,12 @@ struct ss_env {
   int helpers;          // -1 auto, else 0 / 1 / 3 helper wavefronts (env SS_HELPERS)
   int helper_max_groups;  // auto: use the helper wavefront up to this many 32-env groups
   int mirror;           // env.set_mirror flag (kept; see ss_set_mirror)
+  ss::PeerTable* peer_table;   // device copy of the peer-store table (ss_peer_connect), or null
+  uint32_t* peer_counter;
+  uint32_t* peer_error;
+  uint32_t* my_flags[4];       // this rank's flag array [G] of every ring slot (fine-grained)
+  int peer_count;
+  int peer_slots;
 };
 
 namespace {
@@ -201,6 +208,9 @@ void ss_destroy(ss_env* env) {
   if (env->P.terrain) (void)hipFree(env->P.terrain);
   if (env->prob_shared) (void)hipFree(env->prob_shared);
   if (env->dk) (void)hipFree(env->dk);
+  if (env->peer_table) (void)hipFree(env->peer_table);
+  if (env->peer_counter) (void)hipFree(env->peer_counter);
+  if (env->peer_error) (void)hipFree(env->peer_error);
   if (env->prob_env) (void)hipFree(env->prob_env);
   if (env->obs_rows) (void)hipFree(env->obs_rows);
   if (env->P.prof) (void)hipFree(env->P.prof);
@@ -222,7 +232,7 @@ int ss_reset(ss_env* env, float* obs, void* stream) {
 int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!act || !obs || !rew || !done) return fail(SS_ERR_INVALID, "act/obs/rew/done must be device pointers");
-  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0};
   return launch_step<false>(env, io, (hipStream_t)stream);
 }
 
@@ -234,7 +244,7 @@ int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, 
   const int32_t chunk = steps_per_launch > 0 ? steps_per_launch : 1000;     // K = 1000 steps per launch
   for (int32_t k = 0; k < num_steps; k += chunk) {
     const int32_t ns = num_steps - k < chunk ? num_steps - k : chunk;
-    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr, ns};
+    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr, ns, nullptr, 0};
     int rc = ns == 1 ? launch_step<true>(env, io, (hipStream_t)stream) : launch_rollout(env, io, (hipStream_t)stream);
     if (rc != SS_OK) return rc;
   }
@@ -245,8 +255,98 @@ int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64
                    void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!packed || (!act && !use_random_actions)) return fail(SS_ERR_INVALID, "packed (and act, unless random) must be set");
-  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1};
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, nullptr, 0};
   return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
+}
+
+// ---- peer-store all-gather (multi-GPU without a collective library in the data path)
+int ss_peer_alloc(void** out, uint64_t bytes) {
+  if (!out || bytes == 0) return fail(SS_ERR_INVALID, "bad argument");
+  SS_HIP(hipExtMallocWithFlags(out, (size_t)bytes, hipDeviceMallocFinegrained));
+  SS_HIP(hipMemset(*out, 0, (size_t)bytes));
+  SS_HIP(hipDeviceSynchronize());
+  return SS_OK;
+}
+int ss_peer_free(void* ptr) {
+  if (ptr) SS_HIP(hipFree(ptr));
+  return SS_OK;
+}
+int ss_peer_ipc_handle(void* ptr, void* handle64) {
+  if (!ptr || !handle64) return fail(SS_ERR_INVALID, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "ipc handle size");
+  SS_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle64), ptr));
+  return SS_OK;
+}
+int ss_peer_ipc_open(const void* handle64, void** out) {
+  if (!handle64 || !out) return fail(SS_ERR_INVALID, "null argument");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, sizeof h);
+  SS_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+  return SS_OK;
+}
+int ss_peer_ipc_close(void* ptr) {
+  if (ptr) SS_HIP(hipIpcCloseMemHandle(ptr));
+  return SS_OK;
+}
+
+int ss_peer_connect(ss_env* env, int32_t count, int32_t rank, int32_t slots, float* const* gather_bufs, uint32_t* const* flag_bufs) {
+  if (!env || !gather_bufs || !flag_bufs) return fail(SS_ERR_INVALID, "null argument");
+  if (count < 1 || count > ss::kMaxPeers || rank < 0 || rank >= count) return fail(SS_ERR_INVALID, "need 1 <= count <= 8, 0 <= rank < count");
+  if (slots < 1 || slots > kMaxPeerSlots) return fail(SS_ERR_INVALID, "need 1 <= slots <= 4");
+  SS_HIP(hipSetDevice(env->device));
+  if (!env->peer_counter) {
+    SS_HIP(hipMalloc(&env->peer_counter, sizeof(uint32_t)));
+    SS_HIP(hipMalloc(&env->peer_error, sizeof(uint32_t)));
+    SS_HIP(hipMalloc(&env->peer_table, sizeof(ss::PeerTable) * kMaxPeerSlots));
+  }
+  SS_HIP(hipDeviceSynchronize());
+  SS_HIP(hipMemset(env->peer_counter, 0, sizeof(uint32_t)));
+  SS_HIP(hipMemset(env->peer_error, 0, sizeof(uint32_t)));
+  ss::PeerTable t[kMaxPeerSlots];
+  std::memset(t, 0, sizeof t);
+  for (int s = 0; s < slots; ++s) {
+    for (int p = 0; p < count; ++p) {
+      if (!gather_bufs[s * count + p] || !flag_bufs[s * count + p]) return fail(SS_ERR_INVALID, "null peer buffer");
+      t[s].dst[p] = gather_bufs[s * count + p];
+      t[s].flag[p] = flag_bufs[s * count + p];
+    }
+    t[s].done_counter = env->peer_counter;
+    t[s].count = count;
+    t[s].rank = rank;
+    t[s].n_local = env->P.n;
+    env->my_flags[s] = flag_bufs[s * count + rank];
+  }
+  SS_HIP(hipMemcpy(env->peer_table, t, sizeof t, hipMemcpyHostToDevice));
+  env->peer_count = count;
+  env->peer_slots = slots;
+  return SS_OK;
+}
+
+int ss_step_packed_peers(ss_env* env, const float* act, int use_random_actions, uint64_t t, int32_t slot, uint32_t step_id,
+                         float* packed, ss_info* info, void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (!env->peer_table) return fail(SS_ERR_INVALID, "ss_peer_connect has not been called");
+  if (slot < 0 || slot >= env->peer_slots) return fail(SS_ERR_INVALID, "slot out of range");
+  if (!act && !use_random_actions) return fail(SS_ERR_INVALID, "act must be set unless random");
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, env->peer_table + slot, step_id};
+  return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
+}
+
+int ss_peer_wait(ss_env* env, int32_t slot, uint32_t step_id, void* stream) {
+  if (!env || !env->peer_table) return fail(SS_ERR_INVALID, "ss_peer_connect has not been called");
+  if (slot < 0 || slot >= env->peer_slots) return fail(SS_ERR_INVALID, "slot out of range");
+  SS_HIP(hipSetDevice(env->device));
+  hipLaunchKernelGGL(ss::peer_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)env->my_flags[slot],
+                     env->peer_count, step_id, env->peer_error);
+  SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+int ss_peer_error(ss_env* env, uint32_t* out) {
+  if (!env || !out || !env->peer_error) return fail(SS_ERR_INVALID, "bad argument");
+  SS_HIP(hipSetDevice(env->device));
+  SS_HIP(hipMemcpy(out, env->peer_error, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SS_OK;
 }
 
 int ss_random_actions(ss_env* env, uint64_t t, float* act, void* stream) {

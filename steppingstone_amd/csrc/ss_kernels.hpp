@@ -277,6 +277,20 @@ SSD void env_reset(const Params& P, int e, Dyn& s, Cache& c, uint32_t& ctr, floa
   pot = -planar_dist(c.p[1], s.pos) / kDt;
 }
 
+// Peer-to-peer all-gather fused into the step kernel (multi-GPU, ss_step_packed_peers): every workgroup stores its rows of
+// the packed block straight into each peer's gather buffer (xGMI stores into fine-grained memory) instead of a local
+// buffer that a collective then ships.  Completion: every workgroup fences (system scope) and counts itself; the last
+// one of a launch publishes flag_value in each peer's flag word of this rank.
+constexpr int kMaxPeers = 8;
+struct PeerTable {
+  float* dst[kMaxPeers];        // peer p's gather buffer [G * n_local, 62] (p == my rank: my own)
+  uint32_t* flag[kMaxPeers];    // peer p's flag array [G]
+  uint32_t* done_counter;       // local, device scope: workgroups finished (monotonic)
+  int count;                    // G
+  int rank;                     // my rank: rows [rank * n_local, (rank+1) * n_local) and flag[p][rank] are mine
+  int n_local;
+};
+
 struct StepIO {
   const float* act;   // [N,21] or null when actions are generated on device
   float* obs;         // [N,60]
@@ -287,6 +301,8 @@ struct StepIO {
   float* packed;      // optional [N,62] = obs | rew | done(0/1): the block the multi-GPU all-gather ships; when set,
                       // obs / rew / done above may be null
   int nsteps;         // control steps per launch (rollout kernels; 1 otherwise)
+  const PeerTable* peers;   // optional (device memory): also store the packed block into every peer's gather buffer
+  uint32_t flag_value;      // what the last workgroup publishes in the peers' flag words (the step number)
 };
 
 // draw of the reset joint noise for global joint gj (PHYSICS.md section 7); r = the 6 Philox blocks of the reset
@@ -670,6 +686,32 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       const uint32_t* is = reinterpret_cast<const uint32_t*>(lds) + kEnvsPerWave * kObsStride;
       for (int g = lane; g < nvalid * 5; g += kWave) ig[g] = is[g];
     }
+    if constexpr (!ROLLOUT) {
+      if (io.peers) {
+        constexpr int kPack = SS_OBS_DIM + 2;
+        const PeerTable* T = io.peers;
+        const int G = T->count;
+        const size_t row0 = (size_t)T->rank * (size_t)T->n_local + (size_t)env0;
+#pragma unroll 1
+        for (int p = 0; p < G; ++p) {
+          float* pg = T->dst[p] + row0 * kPack;
+#pragma unroll 1
+          for (int g = lane; g < nvalid * kPack; g += kWave) {
+            const int el = g / kPack, idx = g - el * kPack;
+            pg[g] = lds[el * kObsStride + idx];
+          }
+        }
+        __threadfence_system();                                   // my rows are visible to every agent ...
+        if (lane == 0) {
+          const uint32_t prev = atomicAdd(T->done_counter, 1u);   // ... before I count myself
+          if ((prev + 1u) % gridDim.x == 0u) {                    // last workgroup of this launch (launches are stream-ordered)
+            __threadfence_system();
+            for (int p = 0; p < G; ++p)
+              __hip_atomic_store(T->flag[p] + T->rank, io.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+    }
   }
 #endif
 #undef SS_OBS
@@ -747,6 +789,21 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
   }
 }
 #endif  // SS_HOST_HARNESS
+
+// Consumer side of the peer-store all-gather: lane r waits until peer r has published `value` (or a later step) in this
+// rank's flag array.  Bounded spin: on time-out it raises *error instead of hanging the GPU.
+#ifndef SS_HOST_HARNESS
+__global__ void peer_wait_kernel(const uint32_t* flags, int count, uint32_t value, uint32_t* error) {
+  const int r = threadIdx.x;
+  if (r >= count) return;
+  for (long long it = 0; it < (1ll << 26); ++it) {
+    const uint32_t v = __hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int32_t)(v - value) >= 0) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *error = 1u + (uint32_t)r;
+}
+#endif
 
 // hook updates, stream-ordered (ss_api.hip)
 #ifndef SS_HOST_HARNESS

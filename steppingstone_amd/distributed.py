@@ -26,7 +26,7 @@ DEPTH = 8
 class ShardedVecEnv:
     """Wraps this rank's local vec env (any object with .step / .reset / .num_envs returning device tensors)."""
 
-    def __init__(self, local_env, group=None):
+    def __init__(self, local_env, group=None, peer_gather=None):
         self.local = local_env
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -61,6 +61,14 @@ class ShardedVecEnv:
         self._flat_all = torch.zeros(self._chunk * self.world, dtype=torch.float32, device=dev)
         self._flat_packed = self._flat[:self.n_local * PACK].view(self.n_local, PACK)
         self._flat_info = self._flat[self.n_local * PACK:].view(torch.int32).view(self.n_local, INFO)
+        # peer-store exchange instead of the RCCL all-gather (steppingstone_amd/peer.py): opt-in, one node, GPUs only
+        if peer_gather is None:
+            peer_gather = os.environ.get("SS_PEER_GATHER") == "1"
+        self._peer = None
+        if peer_gather and self._collective and self.device.type == "cuda":
+            from .peer import PeerGather
+            self._peer = PeerGather.connect_processes(local_env, group)
+            self._info_all = torch.zeros((self.num_envs, INFO), dtype=torch.int32, device=dev)
 
     # -- helpers
     def local_slice(self):
@@ -114,6 +122,12 @@ class ShardedVecEnv:
         if a.shape[0] == self.num_envs and self.world > 1:
             a = a[self.local_slice()]
         assert a.shape == (self.n_local, ACT_DIM)
+        if self._peer is not None:
+            # kernel -> every peer's gather buffer; the five info words per env follow in one small collective
+            slot = self._peer.step(actions=a, info=self._flat_info)
+            dist.all_gather_into_tensor(self._info_all, self._flat_info, group=self.group)
+            gobs, grew, gdone = self._split(self._peer.wait(slot))
+            return gobs, grew, gdone, self._info_dict(self._info_all)
         self.local.step_packed(self._flat_packed, actions=a, info=self._flat_info)
         packed, info = self._gather_flat()
         gobs, grew, gdone = self._split(packed)
@@ -122,6 +136,13 @@ class ShardedVecEnv:
     def rollout_random(self, num_steps, t0=0, gather=True):
         """Benchmark path: each of num_steps steps = one local kernel launch writing the packed block + (when
         gather) one asynchronous all-gather of it, overlapped with the following steps' kernels."""
+        if self._peer is not None and gather:
+            # In-order on the launch stream: [step t] [wait t] [step t+1] ...  Seeing peer p's flag of step t+1 implies p
+            # is past its wait of step t, so writing step t+2 into the slot of step t (ring of 2) cannot race p's reads.
+            g = None
+            for k in range(num_steps):
+                g = self._peer.wait(self._peer.step(actions=None, t=t0 + k))
+            return self._split(g)
         slot = 0
         for k in range(num_steps):
             slot = k % DEPTH
@@ -171,4 +192,7 @@ class ShardedVecEnv:
         return out
 
     def close(self):
+        if self._peer is not None:
+            self._peer.close()
+            self._peer = None
         self.local.close()
