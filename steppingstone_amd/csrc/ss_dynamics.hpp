@@ -352,6 +352,90 @@ SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
   return o;
 }
 
+// Forward kinematics of spine + own leg and contact detection of the own sole's four corners against the three active
+// stones (PHYSICS.md 3.3).  Inputs: cos / sin of joints 0..7, base rotation, base position and stones from LDS.
+struct DetectOut {
+  float Rf[3][3];          // foot orientation (world)
+  float pen[4];            // penetration depth per corner
+  int active;              // bit k: corner k touches a stone
+  int cslot;               // 2 bits per corner: which stone slot
+};
+template <class Model>
+SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], const Lds& L, DetectOut& o, FootReport& fr) {
+  float Rf[3][3], pf[3];
+  {
+    float Rw[9][3][3], pw[9][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      pw[0][a] = L.s(S_POS + a);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rw[0][a][c] = Rb[a][c];
+    }
+    static_for<0, 8>([&](auto Jc) {
+      constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
+      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
+      constexpr float rx = Model::r[j][0], ry = Model::r[j][1], rz = Model::r[j][2];
+      float c = cs8[j], sn = sn8[j];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float o_ = pw[p][r];
+        SS_ACC(o_, rx, Rw[p][r][0]); SS_ACC(o_, ry, Rw[p][r][1]); SS_ACC(o_, rz, Rw[p][r][2]);
+        pw[b][r] = o_;
+        Rw[b][r][ai] = c * Rw[p][r][ai] + sn * Rw[p][r][aj];
+        Rw[b][r][aj] = c * Rw[p][r][aj] - sn * Rw[p][r][ai];
+        Rw[b][r][ax] = Rw[p][r][ax];
+      }
+    });
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      pf[a] = pw[RFOOT][a];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Rf[a][c] = Rw[RFOOT][a][c]; o.Rf[a][c] = Rf[a][c]; }
+    }
+  }
+  int active = 0, cslot = 0;
+  fr.contact = 0;
+  fr.on_target = 0;
+  fr.sole[0] = fr.sole[1] = fr.sole[2] = 0.f;
+  {
+    float sp[3][3], sn_[3][3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { sp[sl][i] = L.s(S_STP + sl * 3 + i); sn_[sl][i] = L.s(S_STN + sl * 3 + i); }
+    static_for<0, 4>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
+      float P[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        P[r] = pf[r] + Rf[r][0] * cx + Rf[r][1] * cy + Rf[r][2] * cz;
+        fr.sole[r] += 0.25f * P[r];
+      }
+      float best = 0.f;
+      int slot = -1;
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        float dx = P[0] - sp[sl][0], dy = P[1] - sp[sl][1], dz = P[2] - sp[sl][2];
+        float d = dx * sn_[sl][0] + dy * sn_[sl][1] + dz * sn_[sl][2];
+        float lx = dx - d * sn_[sl][0], ly = dy - d * sn_[sl][1], lz = dz - d * sn_[sl][2];
+        float rho2 = lx * lx + ly * ly + lz * lz;
+        bool hit = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2) && (d < best);
+        if (hit) { best = d; slot = sl; }
+      }
+      o.pen[k] = -best;
+      if (slot >= 0) {
+        active |= 1 << k;
+        cslot |= slot << (2 * k);
+        fr.contact = 1;
+        if (slot == 1) fr.on_target = 1;
+      }
+    });
+  }
+  o.active = active;
+  o.cslot = cslot;
+}
+
 #ifndef SS_HOST_HARNESS
 // Helper wavefront of the small-batch variant: between the two workgroup barriers of a substep it computes the
 // contact operators of its column pairs from the joint records the main wavefront handed over, while the main
@@ -710,80 +794,15 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   SS_MEMBAR();
   SS_PROF(5);
 
-  // ---- detect: FK of spine + own leg, own sole corners vs stones
-  float Rf[3][3], pf[3];
+  // ---- detect: FK of spine + own leg, own sole corners vs stones.  (Round 2 measured this on helper 0, overlapped with
+  // pass 2: the main wavefront then waits for the operators at barrier #2 instead -- 0.0685 vs 0.0654 ms/step; rejected.)
+  DetectOut det;
   {
-    float Rw[9][3][3], pw[9][3];
+    float cs8[8], sn8[8];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      pw[0][a] = L.s(S_POS + a);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Rw[0][a][c] = Rb[a][c];
-    }
-    static_for<0, 8>([&](auto Jc) {
-      constexpr int j = decltype(Jc)::value, b = j + 1, p = kParent[j], ax = kAxis[j];
-      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-      constexpr float rx = Model::r[j][0], ry = Model::r[j][1], rz = Model::r[j][2];
-      float c = jc.r[j].cs, sn = jc.r[j].sn;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        float o = pw[p][r];
-        SS_ACC(o, rx, Rw[p][r][0]); SS_ACC(o, ry, Rw[p][r][1]); SS_ACC(o, rz, Rw[p][r][2]);
-        pw[b][r] = o;
-        Rw[b][r][ai] = c * Rw[p][r][ai] + sn * Rw[p][r][aj];
-        Rw[b][r][aj] = c * Rw[p][r][aj] - sn * Rw[p][r][ai];
-        Rw[b][r][ax] = Rw[p][r][ax];
-      }
-    });
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      pf[a] = pw[RFOOT][a];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Rf[a][c] = Rw[RFOOT][a][c];
-    }
+    for (int k = 0; k < 8; ++k) { cs8[k] = jc.r[k].cs; sn8[k] = jc.r[k].sn; }
+    fk_detect<Model>(cs8, sn8, Rb, L, det, fr);
   }
-  int active = 0;          // bit k: corner k of this lane's foot
-  int cslot = 0;           // 2 bits per corner: stone slot
-  float pen[4];
-  fr.contact = 0;
-  fr.on_target = 0;
-  fr.sole[0] = fr.sole[1] = fr.sole[2] = 0.f;
-  {
-    float sp[3][3], sn_[3][3];
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { sp[sl][i] = L.s(S_STP + sl * 3 + i); sn_[sl][i] = L.s(S_STN + sl * 3 + i); }
-    static_for<0, 4>([&](auto Kc) {
-      constexpr int k = decltype(Kc)::value;
-      constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-      float P[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        P[r] = pf[r] + Rf[r][0] * cx + Rf[r][1] * cy + Rf[r][2] * cz;
-        fr.sole[r] += 0.25f * P[r];
-      }
-      float best = 0.f;
-      int slot = -1;
-#pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
-        float dx = P[0] - sp[sl][0], dy = P[1] - sp[sl][1], dz = P[2] - sp[sl][2];
-        float d = dx * sn_[sl][0] + dy * sn_[sl][1] + dz * sn_[sl][2];
-        float lx = dx - d * sn_[sl][0], ly = dy - d * sn_[sl][1], lz = dz - d * sn_[sl][2];
-        float rho2 = lx * lx + ly * ly + lz * lz;
-        bool hit = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2) && (d < best);
-        if (hit) { best = d; slot = sl; }
-      }
-      pen[k] = -best;
-      if (slot >= 0) {
-        active |= 1 << k;
-        cslot |= slot << (2 * k);
-        fr.contact = 1;
-        if (slot == 1) fr.on_target = 1;
-      }
-    });
-  }
-  const int pair_active = active | xchg_i(active);   // both lanes must take the contact branch together
   SS_PROF(6);
 
   // ---- contact solve
@@ -796,6 +815,10 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (HELPERS > 0) __syncthreads();   // #2: the helper wavefront(s) have written G, T and Lambda_own
 #endif
+  const int active = det.active, cslot = det.cslot;
+  const float (&Rf)[3][3] = det.Rf;
+  const float (&pen)[4] = det.pen;
+  const int pair_active = active | xchg_i(active);   // both lanes must take the contact branch together
 #ifdef SS_ABLATE_CONTACT
   if (false) {
 #else
@@ -884,9 +907,10 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     constexpr float mu = Model::friction;
     ssf2 Vp[3] = {{V[0], V[1]}, {V[2], V[3]}, {V[4], V[5]}};
     ssf2 Wp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll 1
-    for (int it = 0; it < kPgsIters; ++it) {
-      ssf2 dWp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    ssf2 dWp[3];
+    auto sweep = [&]() {           // Gauss-Seidel over the own foot's 12 rows
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dWp[i] = ssf2{0.f, 0.f};
       static_for<0, 12>([&](auto Rc) {
         constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
         ssf2 acc = rWp[row][0] * Vp[0];
@@ -906,6 +930,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) { Vp[i] = rYp[row][i] * dl2 + Vp[i]; dWp[i] = rWp[row][i] * dl2 + dWp[i]; }
       });
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Wp[i] += dWp[i];
+    };
+#ifdef SS_PGS_NO_PEEL
+    constexpr int kCoupled = kPgsIters;
+#else
+    constexpr int kCoupled = kPgsIters - 1;   // after the last sweep nothing reads the foot twist any more: its coupling is dead
+#endif
+#pragma unroll 1
+    for (int it = 0; it < kCoupled; ++it) {
+      sweep();
       // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
       // this foot through T
       ssf2 dpp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -931,9 +966,10 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           Vp[i] = ssf2{c.x, c.y} * s2 + Vp[i];
         }
       }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Wp[i] += dWp[i];
     }
+#ifndef SS_PGS_NO_PEEL
+    sweep();
+#endif
     SV W = {{Wp[0].x, Wp[0].y, Wp[1].x}, {Wp[1].y, Wp[2].x, Wp[2].y}};
     SS_PROF(9);
     // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down

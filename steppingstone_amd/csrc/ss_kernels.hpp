@@ -132,12 +132,25 @@ SSD float planar_dist(const float a[3], const float b[3]) {
   return sqrtf(dx * dx + dy * dy);
 }
 
-SSD void target_features(const float pos[3], float yaw, const float sp[3], const float tilt[2], float o[5]) {
+// roll and pitch of the base (PHYSICS.md 5), and cos / sin of its yaw WITHOUT the angle: yaw = atan2(B, A) with
+// A = 1 - 2(y^2 + z^2), B = 2(wz + xy), so (cos yaw, sin yaw) = (A, B) / |(A, B)| (degenerate |(A,B)| = 0: yaw = 0).
+SSD void quat_roll_pitch_cs(const float q[4], float& roll, float& pitch, float& cy, float& sy) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  roll = atan2f(2.f * (w * x + y * z), 1.f - 2.f * (x * x + y * y));
+  pitch = asinf(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
+  float A = 1.f - 2.f * (y * y + z * z), B = 2.f * (w * z + x * y);
+  float n2 = A * A + B * B;
+  float inv = SS_RSQRT(fmaxf(n2, 1e-30f));
+  cy = n2 > 1e-30f ? A * inv : 1.f;
+  sy = n2 > 1e-30f ? B * inv : 0.f;
+}
+
+// target block of the observation (PHYSICS.md 5): [sin(dtheta) d, cos(dtheta) d, dz, x_tilt, y_tilt] with dtheta the
+// bearing of the stone relative to the body yaw and d the planar distance -- i.e. the planar offset rotated by -yaw:
+// sin(a - yaw) d = dy cos(yaw) - dx sin(yaw), cos(a - yaw) d = dx cos(yaw) + dy sin(yaw).  No atan2 / sincos needed.
+SSD void target_features(const float pos[3], float cy, float sy, const float sp[3], const float tilt[2], float o[5]) {
   float dx = sp[0] - pos[0], dy = sp[1] - pos[1], dz = sp[2] - pos[2];
-  float d = sqrtf(dx * dx + dy * dy), ang = atan2f(dy, dx) - yaw;
-  float sa, ca;
-  sincosf(ang, &sa, &ca);
-  o[0] = sa * d; o[1] = ca * d; o[2] = dz; o[3] = tilt[0]; o[4] = tilt[1];
+  o[0] = dy * cy - dx * sy; o[1] = dx * cy + dy * sy; o[2] = dz; o[3] = tilt[0]; o[4] = tilt[1];
 }
 
 SSD float clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
@@ -145,15 +158,13 @@ SSD float clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
 // observation (PHYSICS.md section 5) written row-major to obs[60]
 template <class Model>
 SSD void write_obs(const Dyn& s, float z_init, int flags, const Cache& c, float* obs) {
-  float roll, pitch, yaw;
-  quat_rpy(s.quat, roll, pitch, yaw);
+  float roll, pitch, sy, cy;
+  quat_roll_pitch_cs(s.quat, roll, pitch, cy, sy);
   float R[3][3];
   quat_rot(s.quat, R);
   float vw[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) vw[r] = R[r][0] * s.v0.v[0] + R[r][1] * s.v0.v[1] + R[r][2] * s.v0.v[2];
-  float sy, cy;
-  sincosf(yaw, &sy, &cy);
   obs[0] = clip5(s.pos[2] - z_init);
   obs[1] = clip5(cy * vw[0] + sy * vw[1]);
   obs[2] = clip5(-sy * vw[0] + cy * vw[1]);
@@ -170,10 +181,10 @@ SSD void write_obs(const Dyn& s, float z_init, int flags, const Cache& c, float*
   obs[48] = (flags & 1) ? 1.f : 0.f;
   obs[49] = (flags & 2) ? 1.f : 0.f;
   float t[5];
-  target_features(s.pos, yaw, c.p[1], c.tilt[1], t);
+  target_features(s.pos, cy, sy, c.p[1], c.tilt[1], t);
 #pragma unroll
   for (int i = 0; i < 5; ++i) obs[50 + i] = t[i];
-  target_features(s.pos, yaw, c.p[2], c.tilt[2], t);
+  target_features(s.pos, cy, sy, c.p[2], c.tilt[2], t);
 #pragma unroll
   for (int i = 0; i < 5; ++i) obs[55 + i] = t[i];
 }
@@ -509,8 +520,8 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   int bad = timeout ? 1 : 0;                     // TimeLimitMask (common/envs_utils.py:59-65): done at the step limit, whatever else ended it
   d = d || timeout;
   // 9. reward
-  float roll, pitch, yaw;
-  quat_rpy(quat, roll, pitch, yaw);
+  float roll, pitch, cyaw, syaw;                 // of the state the step ended in (before a possible reset)
+  quat_roll_pitch_cs(quat, roll, pitch, cyaw, syaw);
   float posture = 0.f;
   if (!(pitch > -0.2f && pitch < 0.4f)) posture += fabsf(pitch);
   if (!(roll > -0.4f && roll < 0.4f)) posture += fabsf(roll);
@@ -606,10 +617,9 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       float vw[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) vw[i] = R[i][0] * v0.v[0] + R[i][1] * v0.v[1] + R[i][2] * v0.v[2];
-      float r2, p2, y2;
-      quat_rpy(quat, r2, p2, y2);
-      float sy, cy;
-      sincosf(y2, &sy, &cy);
+      // a reset leaves the identity orientation: roll = pitch = yaw = 0 exactly; otherwise the values computed above
+      const float r2 = do_reset ? 0.f : roll, p2 = do_reset ? 0.f : pitch;
+      const float cy = do_reset ? 1.f : cyaw, sy = do_reset ? 0.f : syaw;
       SS_OBS(0) = clip5(pos[2] - z_init);
       SS_OBS(1) = clip5(cy * vw[0] + sy * vw[1]);
       SS_OBS(2) = clip5(-sy * vw[0] + cy * vw[1]);
@@ -619,10 +629,10 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       SS_OBS(48) = (flags & 1) ? 1.f : 0.f;
       SS_OBS(49) = (flags & 2) ? 1.f : 0.f;
       float t[5];
-      target_features(pos, y2, c.p[1], c.tilt[1], t);
+      target_features(pos, cy, sy, c.p[1], c.tilt[1], t);
 #pragma unroll
       for (int i = 0; i < 5; ++i) SS_OBS(50 + i) = t[i];
-      target_features(pos, y2, c.p[2], c.tilt[2], t);
+      target_features(pos, cy, sy, c.p[2], c.tilt[2], t);
 #pragma unroll
       for (int i = 0; i < 5; ++i) SS_OBS(55 + i) = t[i];
       if (io.rew) io.rew[e] = r;
@@ -911,10 +921,10 @@ __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, con
       p2[1] = p1[1] + planar * sph;
       p2[2] = p1[2] + dr * sp;
     }
-    float roll, pitch_b, yaw;
-    quat_rpy(quat, roll, pitch_b, yaw);
+    float roll, pitch_b, cyaw, syaw;
+    quat_roll_pitch_cs(quat, roll, pitch_b, cyaw, syaw);
     float f[5];
-    target_features(pos, yaw, p2, tilt2, f);
+    target_features(pos, cyaw, syaw, p2, tilt2, f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) feat[cell * 5 + i] = f[i];
   }
