@@ -36,6 +36,8 @@ ENV_ID = "Walker3DStepperEnv-v0"
 #                        obs 240 B, rew 4 B, done 1 B, info 20 B = 521 B                                     -> 869 B
 #   K steps per launch:  the 348 B are read once per launch, the 521 B written every step; the epilogue's re-read of
 #                        the 13 bookkeeping words + stone cache is served by L2                 -> 521 + 348/K B
+# roofline.achieved is computed from the 869 B per-unit figure for both launch shapes; the smaller figure of
+# the K-step kernel and the PMC-measured traffic are reported beside it.
 ALGO_READ_B, ALGO_WRITE_B = 348, 521
 HBM_PEAK_GBS = 8000.0
 VALU_FP32_PEAK_TFLOPS = 157.3          # packed-f32 vector peak (MI355X_MICROARCH.md): 256 CUs x 2.4 GHz x 256 flop/clk
@@ -212,7 +214,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Mike / capacity side measurements")
     ap.add_argument("--no-gather", action="store_true", help="N>1: time only the collective-free rollout")
-    ap.add_argument("--no-peer-store", action="store_true", help="N>1: skip the peer-store side measurement")
+    ap.add_argument("--peer-store", action="store_true",
+                    help="N>1: also time the peer-store exchange (steppingstone_amd/peer.py; validated on one GPU only so far)")
     ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
     args = ap.parse_args()
 
@@ -291,13 +294,16 @@ def main():
             el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
             side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
             t_next += K
-            if not args.no_peer_store:
+            if args.peer_store:
                 # the same exchange written by the step kernel itself into every peer's gather buffer (no collective in
                 # the data path; steppingstone_amd/peer.py).  A side row: a failure here never touches the headline value.
                 try:
                     penv = ShardedVecEnv(local, peer_gather=True)
-                    penv.rollout_random(min(W, 50) or 8, t0=t_next, gather=True)
-                    el3, _ = timed(lambda: penv.rollout_random(K, t0=t_next + 50, gather=True))
+                    penv.rollout_random(2, t0=t_next, gather=True)
+                    if penv._peer.error():                      # a flag never arrived: do not spin through K more steps
+                        raise RuntimeError("peer flags timed out in the first two steps")
+                    penv.rollout_random(min(W, 50) or 8, t0=t_next + 2, gather=True)
+                    el3, _ = timed(lambda: penv.rollout_random(K, t0=t_next + 52, gather=True))
                     err = penv._peer.error() if penv._peer is not None else -1
                     side["peer_store"] = {"ms_per_step": 1e3 * el3 / K, "wait_timeouts": err,
                                           "note": "same K steps, packed block stored by the step kernel into every peer's "
@@ -305,7 +311,7 @@ def main():
                     penv._peer.close(); penv._peer = None
                 except Exception as exc:
                     side["peer_store"] = {"ms_per_step": None, "error": repr(exc)[:300]}
-                t_next += K + 50
+                t_next += K + 52
         _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
         kernel_ms_per_step = ev1 / K                       # back-to-back launches on one stream: sum of durations
 
@@ -323,7 +329,11 @@ def main():
         total_envs = n_local * world
         value = total_envs * K / elapsed
         steps_in_launch = spl if multi_step else 1
-        algo_per_env_step = ALGO_WRITE_B + ALGO_READ_B / float(steps_in_launch)
+        # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (869 B per env-step: the state
+        # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 348 B
+        # of state are read once per launch): that figure is reported next to it, as is the PMC-measured traffic.
+        algo_per_env_step = float(ALGO_WRITE_B + ALGO_READ_B)
+        algo_k_step = ALGO_WRITE_B + ALGO_READ_B / float(steps_in_launch)
         launch_ms = kernel_ms_per_step * steps_in_launch
         algo_per_launch = algo_per_env_step * n_local * steps_in_launch
         achieved = algo_per_launch / (launch_ms * 1e-3) / 1e9
@@ -357,6 +367,7 @@ def main():
                          "kernel": kernel, "kernel_ms": launch_ms, "kernel_ms_per_step": kernel_ms_per_step,
                          "algorithmic_bytes_per_env_step": algo_per_env_step,
                          "algorithmic_bytes_per_launch": algo_per_launch,
+                         "algorithmic_bytes_per_env_step_with_lds_resident_state": algo_k_step,
                          "note": pmc_note(pmc), "note_source": pmc_src},
         }
         out.update(side)

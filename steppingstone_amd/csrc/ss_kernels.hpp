@@ -806,7 +806,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
 __global__ void peer_wait_kernel(const uint32_t* flags, int count, uint32_t value, uint32_t* error) {
   const int r = threadIdx.x;
   if (r >= count) return;
-  for (long long it = 0; it < (1ll << 26); ++it) {
+  for (long long it = 0; it < (1ll << 23); ++it) {     // ~1 s
     const uint32_t v = __hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int32_t)(v - value) >= 0) return;
     __builtin_amdgcn_s_sleep(8);
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(kWave) void obs_kernel(Params P, float* obs) {
 // then one 256-thread workgroup per env computes the 121 x 5 target features (one lane per cell) and streams the
 // [121,60] block out as 1815 coalesced float4 -- the one HBM-bound kernel of the path (29 KB written per env).
 #ifndef SS_TEMP_THREADS
-#define SS_TEMP_THREADS 256
+#define SS_TEMP_THREADS 240            // a multiple of 15: every thread keeps ONE float4 column of the row
 #endif
 constexpr int kTempThreads = SS_TEMP_THREADS;
 __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, const float* __restrict__ obs_rows, float* out) {
@@ -921,24 +921,37 @@ __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, con
       p2[1] = p1[1] + planar * sph;
       p2[2] = p1[2] + dr * sp;
     }
-    float roll, pitch_b, cyaw, syaw;
-    quat_roll_pitch_cs(quat, roll, pitch_b, cyaw, syaw);
+    float cyaw, syaw;                      // yaw only: (cos, sin) = (A, B) / |(A, B)| as in quat_roll_pitch_cs
+    {
+      const float A = 1.f - 2.f * (quat[2] * quat[2] + quat[3] * quat[3]), B = 2.f * (quat[0] * quat[3] + quat[1] * quat[2]);
+      const float n2 = A * A + B * B, inv = rsqrtf(fmaxf(n2, 1e-30f));
+      cyaw = n2 > 1e-30f ? A * inv : 1.f;
+      syaw = n2 > 1e-30f ? B * inv : 0.f;
+    }
     float f[5];
     target_features(pos, cyaw, syaw, p2, tilt2, f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) feat[cell * 5 + i] = f[i];
   }
   __syncthreads();
+  // Measured in round 2 (profiles/r02_*_temp_states.txt): this one-workgroup-per-env shape writes 5.0-5.3 TB/s at 32768
+  // envs (a torch fill of the same buffer: 6.9 TB/s) -- and it stays there with the feature computation removed, with 60-
+  // or 120-thread workgroups, with persistent workgroups (4.1-5.0 TB/s) and with one workgroup per 16 rows (1.8 TB/s,
+  // latency-bound): the limit is the write pattern of 29,040-byte blocks, not the prologue.
   constexpr int kRow4 = SS_OBS_DIM / 4;                      // 15 float4 per row
+  static_assert(kTempThreads % kRow4 == 0, "a thread must stay in its column");
+  constexpr int kRowsPerPass = kTempThreads / kRow4;
   float4* o4 = reinterpret_cast<float4*>(out) + (size_t)e * (SS_NCELL * kRow4);
   const float4* b4 = reinterpret_cast<const float4*>(base);
-  for (int i = t; i < SS_NCELL * kRow4; i += kTempThreads) {
-    const int row = i / kRow4, c4 = i - row * kRow4;
-    float4 v = b4[c4 < kRow4 - 1 ? c4 : kRow4 - 2];
+  const int c4 = t % kRow4;
+  const float4 bv = b4[c4 < kRow4 - 1 ? c4 : kRow4 - 2];     // this thread's column of the common part, in registers
+#pragma unroll 1
+  for (int row = t / kRow4; row < SS_NCELL; row += kRowsPerPass) {
+    float4 v = bv;
     const float* f = feat + row * 5;
     if (c4 == kRow4 - 2) v.w = f[0];                         // obs[52..54], obs[55]
     if (c4 == kRow4 - 1) v = make_float4(f[1], f[2], f[3], f[4]);
-    o4[i] = v;          // plain stores: nontemporal ones measured 20 % slower here
+    o4[row * kRow4 + c4] = v;          // plain stores: nontemporal ones measured 20 % slower here
   }
 }
 #endif  // SS_HOST_HARNESS

@@ -371,13 +371,14 @@ def test_bench_rccl_path_on_one_rank():
     env = dict(os.environ, SS_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--peer-store"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     js = json.loads(line)
     assert js["config"]["parallelism"].endswith("+allgather")
     assert js["value"] > 1e6 and js["n_gpus"] == 1
+    assert js["no_gather"]["ms_per_step"] > 0 and js["peer_store"]["ms_per_step"] > 0 and js["peer_store"]["wait_timeouts"] == 0
 
 
 def test_ppo_graph_replay_matches_eager():
