@@ -48,7 +48,25 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+LEARNER_LIB = os.path.join(LIBDIR, "libsslearner.so")
+LEARNER_SRC = os.path.join(CSRC, "ss_learner.hip")
+
+
+def build_learner(force=False, verbose=False):
+    """The fused PPO minibatch step (csrc/ss_learner.hip, include/steppingstone_learner.h): MFMA f32 kernels, its own library."""
+    deps = [LEARNER_SRC, os.path.join(PKG, "..", "include", "steppingstone_learner.h")]
+    if not force and os.path.exists(LEARNER_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LEARNER_LIB) for d in deps):
+        return LEARNER_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", LEARNER_SRC, "-o", LEARNER_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LEARNER_LIB
+
+
 def build(force=False, verbose=False):
+    build_learner(force, verbose)
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

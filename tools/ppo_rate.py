@@ -7,14 +7,15 @@ import torch
 from steppingstone_amd import ppo
 from steppingstone_amd.envs import SteppingStoneVecEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for use_graph, mb in ((False, 1024), (True, 1024), (True, 4096), (True, 16384)):
+for use_graph, mb, learner in ((False, 1024, "torch"), (True, 1024, "torch"), (True, 4096, "torch"), (True, 16384, "torch"),
+                              (True, 1024, "fused"), (True, 4096, "fused"), (True, 16384, "fused")):
     envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n, seed=8, device="cuda:0", return_numpy=False)
     stamps = []
     def log(st):
         torch.cuda.synchronize()
         stamps.append((time.time(), st["total_num_steps"], st["mean_rew"]))
-    ac, hist = ppo.train(envs, 10, num_steps=32, ppo_epoch=10, mini_batch_size=mb, log=log, use_graph=use_graph)
+    ac, hist = ppo.train(envs, 10, num_steps=32, ppo_epoch=10, mini_batch_size=mb, log=log, use_graph=use_graph, learner=learner)
     fps = (stamps[-1][1] - stamps[3][1]) / (stamps[-1][0] - stamps[3][0])
-    print("%d envs  graph=%d  minibatch %5d: %7.0f frames/s steady state, mean episode return %.1f -> %.1f" %
-          (n, use_graph, mb, fps, stamps[0][2], stamps[-1][2]), flush=True)
+    print("%d envs  graph=%d  learner=%-5s minibatch %5d: %7.0f frames/s steady state, mean episode return %.1f -> %.1f" %
+          (n, use_graph, learner, mb, fps, stamps[0][2], stamps[-1][2]), flush=True)
     envs.close()
