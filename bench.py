@@ -13,9 +13,12 @@ step = 4 physics substeps, contact solve, reward, termination, auto-reset, 60-fl
   N = 1: the K timed steps run through ss_rollout_random's multi-step kernel (up to 1000 control steps
          per launch, state resident in LDS between steps, outputs and the HBM state copy written every step); the
          one-launch-per-step path (what a policy-in-the-loop caller uses) is timed beside it as `per_step_launch`.
-  N > 1: every rank owns 4096 envs (weak scaling) and every step ends with the RCCL all-gather of the packed
-         [4096,62] obs|rew|done block (BASELINE configs[3]), so steps are single launches; the same K steps without
-         the collective are timed as `no_gather`.
+  N > 1: every rank owns 4096 envs (weak scaling) and every step's packed [4096,62] obs|rew|done block is all-gathered
+         over RCCL (BASELINE configs[3]).  The same multi-step kernel runs here too: 32 control steps per launch, each
+         step's block written to its own slot, ONE all-gather per 32-step chunk under the next chunk's kernel (same bytes
+         per step on the wire, 32 x fewer collectives) -- so the N = 1 and N > 1 lines time the same kernel and their ratio
+         is the cost of the exchange, not of a different launch shape.  Side rows: `no_gather` (same K steps, no
+         collective), `per_step_gather` (one launch + one all-gather per step: what a policy-in-the-loop caller pays).
 State is resident in HBM before the timed region.  Rank 0 prints ONE JSON line with `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -214,6 +217,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the Mike / capacity side measurements")
     ap.add_argument("--no-gather", action="store_true", help="N>1: time only the collective-free rollout")
+    ap.add_argument("--per-step-exchange", action="store_true",
+                    help="N>1: headline = one launch + one all-gather per step instead of 32-step chunks")
     ap.add_argument("--peer-store", action="store_true",
                     help="N>1: also time the peer-store exchange (steppingstone_amd/peer.py; validated on one GPU only so far)")
     ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
@@ -273,8 +278,11 @@ def main():
         return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
     K, W = args.steps, args.warmup
+    chunked = use_dist and not args.per_step_exchange
     if multi_step:
         run = lambda k, t0: local.rollout_random(k, t0=t0, steps_per_launch=spl)            # noqa: E731
+    elif chunked:
+        run = lambda k, t0: env.rollout_random_chunked(k, t0=t0, gather=gather)             # noqa: E731
     else:
         run = lambda k, t0: env.rollout_random(k, t0=t0, gather=gather)                     # noqa: E731
     if W:
@@ -291,9 +299,18 @@ def main():
         kernel_ms_per_step = main_ev_ms / K
     else:
         if use_dist and gather:
-            el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
-            side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
-            t_next += K
+            if chunked:
+                el2, _ = timed(lambda: env.rollout_random_chunked(K, t0=t_next, gather=False))
+                side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps, same 32-step launches, no collective"}
+                t_next += K
+                el4, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=True))
+                side["per_step_gather"] = {"ms_per_step": 1e3 * el4 / K,
+                                           "note": "one kernel launch and one all-gather of [N/G,62] per control step"}
+                t_next += K
+            else:
+                el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
+                side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
+                t_next += K
             if args.peer_store:
                 # the same exchange written by the step kernel itself into every peer's gather buffer (no collective in
                 # the data path; steppingstone_amd/peer.py).  A side row: a failure here never touches the headline value.
@@ -312,15 +329,17 @@ def main():
                 except Exception as exc:
                     side["peer_store"] = {"ms_per_step": None, "error": repr(exc)[:300]}
                 t_next += K + 52
-        _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
+        kspl = 32 if chunked else 1
+        _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=kspl))
         kernel_ms_per_step = ev1 / K                       # back-to-back launches on one stream: sum of durations
 
     t = torch.tensor([elapsed, side.get("no_gather", {}).get("ms_per_step", 0.0),
-                      side.get("peer_store", {}).get("ms_per_step") or 0.0], dtype=torch.float64, device=dev)
+                      side.get("peer_store", {}).get("ms_per_step") or 0.0,
+                      side.get("per_step_gather", {}).get("ms_per_step", 0.0)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0].item())
-    for i, key in ((1, "no_gather"), (2, "peer_store")):
+    for i, key in ((1, "no_gather"), (2, "peer_store"), (3, "per_step_gather")):
         if key in side and side[key].get("ms_per_step"):
             side[key]["ms_per_step"] = float(t[i].item())
             side[key]["value"] = n_local * world / (side[key]["ms_per_step"] * 1e-3)
@@ -328,7 +347,7 @@ def main():
     if rank == 0:
         total_envs = n_local * world
         value = total_envs * K / elapsed
-        steps_in_launch = spl if multi_step else 1
+        steps_in_launch = spl if multi_step else (32 if chunked else 1)
         # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (869 B per env-step: the state
         # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 348 B
         # of state are read once per launch): that figure is reported next to it, as is the PMC-measured traffic.
@@ -337,14 +356,14 @@ def main():
         launch_ms = kernel_ms_per_step * steps_in_launch
         algo_per_launch = algo_per_env_step * n_local * steps_in_launch
         achieved = algo_per_launch / (launch_ms * 1e-3) / 1e9
-        tag = "rollout_" if multi_step else ""
+        tag = "rollout_" if (multi_step or chunked) else ""
         traffic, traffic_src, traffic_rec = recorded_traffic(n_local, tag)
         if traffic is not None:
             traffic *= steps_in_launch                 # per launch of THIS run, like `achieved` (recorded per env-step)
         pmc, pmc_src = recorded_pmc()
         helpers = 3 if n_local <= 8192 else (1 if n_local <= 16384 else 0)
         model = "ModelWalker3D" if "Walker3D" in args.env else "ModelMike"
-        if multi_step:
+        if multi_step or chunked:
             kernel = ("ss::rollout_kernel_helped<%s,%d>" % (model, helpers)) if helpers else "ss::rollout_kernel<%s>" % model
         else:
             kernel = ("ss::step_kernel_helped<%s,true,%d>" % (model, helpers)) if helpers else "ss::step_kernel<%s,true>" % model
@@ -357,7 +376,8 @@ def main():
                                    % (args.env, n_local, args.curriculum, " (flat terrain)" if not args.curriculum else ""),
                        "envs_total": total_envs,
                        "parallelism": "env-shard x%d%s" % (world, "+allgather" if gather else ""),
-                       "ranks": world, "collective": ("RCCL all_gather_into_tensor of [%d,62] f32 per step, %d ranks"
+                       "ranks": world, "collective": (("RCCL all_gather_into_tensor of [32,%d,62] f32 per 32-step chunk, %d ranks"
+                                                       if chunked else "RCCL all_gather_into_tensor of [%d,62] f32 per step, %d ranks")
                                                       % (n_local, world)) if gather else None,
                        "steps_per_launch": steps_in_launch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

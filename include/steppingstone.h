@@ -77,6 +77,11 @@ int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done
  * values afterwards) and the HBM copy of the state; the result is bit-identical for every steps_per_launch. */
 int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, uint64_t t0, float* obs, float* rew,
                       uint8_t* done, ss_info* info, void* stream);
+/* The same multi-step launch writing every step's packed block (see ss_step_packed) at packed[k] of a [num_steps, N, 62]
+ * f32 device buffer: the rollout of a multi-GPU shard whose exchange ships num_steps blocks per collective instead of one
+ * (steppingstone_amd.distributed.ShardedVecEnv.rollout_random: same bytes on the wire, K times fewer collectives and
+ * launches).  One launch; num_steps >= 1. */
+int ss_rollout_random_packed(ss_env* env, int32_t num_steps, uint64_t t0, float* packed, ss_info* info, void* stream);
 /* One step whose results land in ONE packed device buffer [N,62] f32 = obs(60) | rew | done(0/1): the block a
  * multi-GPU shard all-gathers per step (replaces the per-env pipe + shared-memory traffic of
  * common/envs_utils.py:550-558,608-620).  use_random_actions != 0: actions from the benchmark Philox stream at index t. */

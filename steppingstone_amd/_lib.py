@@ -17,7 +17,7 @@ SYMBOLS = [
     "ss_create_temp_states", "ss_get_mirror_indices", "ss_get_state", "ss_set_state", "ss_get_obs", "ss_num_envs",
     "ss_version", "ss_set_sample_prob_device", "ss_debug_calib_copy", "ss_debug_phase_cycles",
     "ss_peer_alloc", "ss_peer_free", "ss_peer_ipc_handle", "ss_peer_ipc_open", "ss_peer_ipc_close", "ss_peer_connect",
-    "ss_step_packed_peers", "ss_peer_wait", "ss_peer_error",
+    "ss_step_packed_peers", "ss_peer_wait", "ss_peer_error", "ss_rollout_random_packed",
 ]
 
 
@@ -47,6 +47,7 @@ def load():
     lib.ss_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.ss_rollout_random.argtypes = [vp, i32, i32, u64, vp, vp, vp, vp, vp]
     lib.ss_step_packed.argtypes = [vp, vp, C.c_int, u64, vp, vp, vp]
+    lib.ss_rollout_random_packed.argtypes = [vp, i32, u64, vp, vp, vp]
     lib.ss_random_actions.argtypes = [vp, u64, vp, vp]
     lib.ss_set_curriculum.argtypes = [vp, i32]
     lib.ss_set_specialist.argtypes = [vp, i32]

@@ -232,7 +232,7 @@ int ss_reset(ss_env* env, float* obs, void* stream) {
 int ss_step(ss_env* env, const float* act, float* obs, float* rew, uint8_t* done, ss_info* info, void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!act || !obs || !rew || !done) return fail(SS_ERR_INVALID, "act/obs/rew/done must be device pointers");
-  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0, 0};
   return launch_step<false>(env, io, (hipStream_t)stream);
 }
 
@@ -244,18 +244,26 @@ int ss_rollout_random(ss_env* env, int32_t num_steps, int32_t steps_per_launch, 
   const int32_t chunk = steps_per_launch > 0 ? steps_per_launch : 1000;     // K = 1000 steps per launch
   for (int32_t k = 0; k < num_steps; k += chunk) {
     const int32_t ns = num_steps - k < chunk ? num_steps - k : chunk;
-    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr, ns, nullptr, 0};
+    ss::StepIO io{nullptr, obs, rew, done, info, t0 + (uint64_t)k, nullptr, ns, nullptr, 0, 0};
     int rc = ns == 1 ? launch_step<true>(env, io, (hipStream_t)stream) : launch_rollout(env, io, (hipStream_t)stream);
     if (rc != SS_OK) return rc;
   }
   return SS_OK;
 }
 
+int ss_rollout_random_packed(ss_env* env, int32_t num_steps, uint64_t t0, float* packed, ss_info* info, void* stream) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  if (!packed) return fail(SS_ERR_INVALID, "packed must be a device pointer to [num_steps, N, 62] floats");
+  if (num_steps < 1) return fail(SS_ERR_INVALID, "num_steps must be >= 1");
+  ss::StepIO io{nullptr, nullptr, nullptr, nullptr, info, t0, packed, num_steps, nullptr, 0, (long long)env->P.n * (SS_OBS_DIM + 2)};
+  return launch_rollout(env, io, (hipStream_t)stream);
+}
+
 int ss_step_packed(ss_env* env, const float* act, int use_random_actions, uint64_t t, float* packed, ss_info* info,
                    void* stream) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
   if (!packed || (!act && !use_random_actions)) return fail(SS_ERR_INVALID, "packed (and act, unless random) must be set");
-  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, nullptr, 0};
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, nullptr, 0, 0};
   return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
 }
 
@@ -328,7 +336,7 @@ int ss_step_packed_peers(ss_env* env, const float* act, int use_random_actions, 
   if (!env->peer_table) return fail(SS_ERR_INVALID, "ss_peer_connect has not been called");
   if (slot < 0 || slot >= env->peer_slots) return fail(SS_ERR_INVALID, "slot out of range");
   if (!act && !use_random_actions) return fail(SS_ERR_INVALID, "act must be set unless random");
-  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, env->peer_table + slot, step_id};
+  ss::StepIO io{act, nullptr, nullptr, nullptr, info, t, packed, 1, env->peer_table + slot, step_id, 0};
   return use_random_actions ? launch_step<true>(env, io, (hipStream_t)stream) : launch_step<false>(env, io, (hipStream_t)stream);
 }
 

@@ -314,6 +314,8 @@ struct StepIO {
   int nsteps;         // control steps per launch (rollout kernels; 1 otherwise)
   const PeerTable* peers;   // optional (device memory): also store the packed block into every peer's gather buffer
   uint32_t flag_value;      // what the last workgroup publishes in the peers' flag words (the step number)
+  long long packed_step_stride;   // rollout kernels: step k of the launch writes its packed block at packed + k * stride
+                                  // (0: every step overwrites the same block)
 };
 
 // draw of the reset joint noise for global joint gj (PHYSICS.md section 7); r = the 6 Philox blocks of the reset
@@ -708,7 +710,11 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
         }
       }
     }
-    if (io.packed) copy_block(io.packed + (size_t)env0 * kPackW, nvalid * kPackW);
+    if (io.packed) {
+      float* pk = io.packed + (size_t)env0 * kPackW;
+      if constexpr (ROLLOUT) pk += (long long)kstep * io.packed_step_stride;
+      copy_block(pk, nvalid * kPackW);
+    }
     if (io.info) {
       uint32_t* ig = reinterpret_cast<uint32_t*>(io.info + env0);
       const uint32_t* is = reinterpret_cast<const uint32_t*>(lds) + kInfoBase;

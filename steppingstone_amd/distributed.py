@@ -21,6 +21,7 @@ from ._lib import ACT_DIM, NCELL, OBS_DIM
 PACK = OBS_DIM + 2
 INFO = 5
 DEPTH = 8
+CHUNK = 32          # control steps per launch / per collective of the chunked rollout exchange
 
 
 class ShardedVecEnv:
@@ -133,9 +134,46 @@ class ShardedVecEnv:
         gobs, grew, gdone = self._split(packed)
         return gobs, grew, gdone, self._info_dict(info)
 
+    def rollout_random_chunked(self, num_steps, t0=0, gather=True, chunk=CHUNK):
+        """Benchmark path, K steps per launch: each chunk of `chunk` control steps is ONE launch of the rollout kernel (state
+        resident in LDS between the steps) writing every step's packed block into a [chunk, N/G, 62] buffer, followed by ONE
+        asynchronous all-gather of the whole chunk -- the same bytes per step on the wire as the per-step exchange, `chunk`
+        times fewer launches and collectives; the collective of chunk c runs under the kernel of chunk c+1 (two buffers).
+        Nothing consumes the observations between the steps of a random-action rollout, so every rank still ends up with every
+        step's global [N, 62] block.  Returns the last step's global (obs, rew, done)."""
+        dev = self.device
+        if getattr(self, "_chunk_local", None) is None or self._chunk_local[0].shape[0] != chunk:
+            self._chunk_local = [torch.zeros((chunk, self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._chunk_all = [torch.zeros((self.world * chunk, self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._chunk_work = [None, None]
+        done_steps, c, last = 0, 0, None
+        while done_steps < num_steps:
+            ns = min(chunk, num_steps - done_steps)
+            b = c & 1
+            if self._chunk_work[b] is not None:            # the collective that last used this pair of buffers
+                self._chunk_work[b].wait()
+                self._chunk_work[b] = None
+            loc = self._chunk_local[b]
+            self.local.rollout_random_packed(loc[:ns], t0=t0 + done_steps)
+            if gather and self._collective:
+                self._chunk_work[b] = dist.all_gather_into_tensor(self._chunk_all[b], loc, group=self.group, async_op=True)
+            last = (b, ns)
+            done_steps += ns
+            c += 1
+        for b in range(2):
+            if self._chunk_work[b] is not None:
+                self._chunk_work[b].wait()
+                self._chunk_work[b] = None
+        b, ns = last
+        if gather and self._collective:
+            g = self._chunk_all[b].view(self.world, chunk, self.n_local, PACK)[:, ns - 1].reshape(self.num_envs, PACK)
+        else:
+            g = self._chunk_local[b][ns - 1]
+        return self._split(g)
+
     def rollout_random(self, num_steps, t0=0, gather=True):
-        """Benchmark path: each of num_steps steps = one local kernel launch writing the packed block + (when
-        gather) one asynchronous all-gather of it, overlapped with the following steps' kernels."""
+        """Benchmark path, one launch per step: each of num_steps steps = one local kernel launch writing the packed block +
+        (when gather) one asynchronous all-gather of it, overlapped with the following steps' kernels."""
         if self._peer is not None and gather:
             # In-order on the launch stream: [step t] [wait t] [step t+1] ...  Seeing peer p's flag of step t+1 implies p
             # is past its wait of step t, so writing step t+2 into the slot of step t (ring of 2) cannot race p's reads.

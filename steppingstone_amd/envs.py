@@ -111,6 +111,9 @@ class HipBackend:
         _lib.check(self.lib.ss_step_packed(self.h, _ptr(act) if act is not None else None, 1 if use_random else 0, int(t),
                                            _ptr(packed), _ptr(info), _stream(self.device)))
 
+    def rollout_random_packed(self, num_steps, t0, packed, info):
+        _lib.check(self.lib.ss_rollout_random_packed(self.h, int(num_steps), int(t0), _ptr(packed), _ptr(info), _stream(self.device)))
+
     def random_actions(self, t, act):
         _lib.check(self.lib.ss_random_actions(self.h, int(t), _ptr(act), _stream(self.device)))
 
@@ -262,6 +265,13 @@ class SteppingStoneVecEnv:
             self._act.copy_(actions.reshape(self.num_envs, ACT_DIM))
         self.backend.step_packed(self._act if actions is not None else None, actions is None, t, packed,
                                  self._info if info is None else info)
+        return packed
+
+    def rollout_random_packed(self, packed, t0=0):
+        """packed: [K, N, 62] device buffer; ONE launch advances K control steps and writes step k's obs | rew | done block at
+        packed[k] (the multi-GPU rollout ships such a chunk per collective)."""
+        assert packed.dim() == 3 and packed.shape[1] == self.num_envs and packed.shape[2] == OBS_DIM + 2 and packed.is_contiguous()
+        self.backend.rollout_random_packed(packed.shape[0], t0, packed, self._info)
         return packed
 
     def random_actions(self, t):

@@ -73,7 +73,7 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.knobs = &K;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
   std::vector<float4> lds((size_t)ss::kLdsSlots * 64);
-  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0};
+  ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0, 0};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
   for (int e = 0; e < n; ++e) {
     PairSync sync;

@@ -45,6 +45,10 @@ class OracleBackend:
         packed[:, 60] = rew
         packed[:, 61] = done.float()
 
+    def rollout_random_packed(self, num_steps, t0, packed, info):
+        for k in range(num_steps):
+            self.step_packed(None, True, t0 + k, packed[k], info)
+
     def random_actions(self, t, act):
         act.copy_(torch.from_numpy(self.o.random_actions(t)))
 

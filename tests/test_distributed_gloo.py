@@ -36,6 +36,9 @@ def _worker(rank, port, ret):
     # benchmark path too: more steps than the ring of gather buffers is deep (asynchronous collectives, batched waits)
     o2, r2, d2 = env.rollout_random(11, t0=100)
     out.append(np.concatenate([o2.numpy(), r2.numpy()[:, None], d2.numpy()[:, None].astype(np.float32)], 1))
+    # chunked exchange (K steps per launch, one collective per chunk): 2 full chunks + a ragged one
+    o3, r3, d3 = env.rollout_random_chunked(11, t0=200, chunk=4)
+    out.append(np.concatenate([o3.numpy(), r3.numpy()[:, None], d3.numpy()[:, None].astype(np.float32)], 1))
     ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
@@ -57,6 +60,9 @@ def test_two_rank_sharding_equals_single_process():
         ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
     for k in range(11):
         ob, r, d, _ = o.step(o.random_actions(100 + k))
+    ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
+    for k in range(11):
+        ob, r, d, _ = o.step(o.random_actions(200 + k))
     ref.append(np.concatenate([ob, r[:, None], d[:, None].astype(np.float32)], 1))
     for rank in range(WORLD):
         assert len(res[rank]) == len(ref)

@@ -260,6 +260,31 @@ def test_rollout_kernel_is_bitwise_equal_to_single_step_launches(n, env_id):
             assert torch.equal(a, b), "variant %d differs" % k
 
 
+def test_packed_rollout_chunks_equal_per_step_packed_blocks():
+    """ss_rollout_random_packed (K steps per launch, step k's obs | rew | done block at packed[k]) == K ss_step_packed
+    launches, bit for bit, for a ragged batch; and ShardedVecEnv's chunked rollout ends in the same state and the same last
+    block as its per-step rollout."""
+    from steppingstone_amd.distributed import ShardedVecEnv
+    n, K = 1000, 37
+    a, b = gpu_env("MikeStepperEnv-v0", n, seed=3, numpy_mode=False), gpu_env("MikeStepperEnv-v0", n, seed=3, numpy_mode=False)
+    for e in (a, b):
+        e.update_curriculum(5)
+        e.reset()
+    ring = torch.zeros((K, n, 62), device="cuda:0")
+    a.rollout_random_packed(ring, t0=5)
+    one = torch.zeros((n, 62), device="cuda:0")
+    for k in range(K):
+        b.step_packed(one, actions=None, t=5 + k)
+        assert torch.equal(ring[k], one), k
+    assert torch.equal(a.get_state(), b.get_state())
+    sa, sb = ShardedVecEnv(a), ShardedVecEnv(b)
+    oa, ra, da = sa.rollout_random_chunked(70, t0=100, chunk=32)     # 2 full chunks + a ragged one
+    ob, rb, db = sb.rollout_random(70, t0=100)
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    assert torch.equal(a.get_state(), b.get_state())
+    a.close(); b.close()
+
+
 def test_hooks_reach_a_captured_graph():
     """the hook state (curriculum, power, sampling grid, auto-reset) lives in HBM, so a hipGraph that
     captured step launches sees updates made after capture.  Graph replay after update_curriculum(5) /
