@@ -41,6 +41,17 @@ int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const 
              int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss, float* stats_out,
              void* stream);
 
+/* The same step with the left-right mirror augmentation of PPO.update (algorithms/ppo.py:57-58 with the mirror_function of
+ * common/envs_utils.py:687-740): the minibatch is doubled, row batch + i being the mirror image of row i.  obs_perm [60] /
+ * act_perm [21] (int32) and obs_sgn [60] / act_sgn [21] (f32) are DEVICE tables: column c of a mirrored row is
+ * sgn[src] * x[src] with src = perm[c] (negate the lateral quantities, then swap right and left limbs).  2 * batch must
+ * fit the workspace (max_batch of ssl_create). */
+int ssl_step_mirror(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
+                    const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred,
+                    const int64_t* idx, int32_t batch, float clip_param, float max_grad_norm, float adam_eps,
+                    int32_t use_clipped_value_loss, float* stats_out, void* stream, const int32_t* obs_perm, const float* obs_sgn,
+                    const int32_t* act_perm, const float* act_sgn);
+
 /* gradient of the last ssl_step (slices reduced, before clipping): device pointer to ssl_num_params floats (tests) */
 const float* ssl_debug_grad(ssl_learner* L);
 

@@ -117,13 +117,23 @@ __device__ __forceinline__ void combine4(const f32x16& acc, float (*red)[16][64]
   }
 }
 
+// Left-right mirror augmentation (common/envs_utils.py:687-740, PPO.update's mirror_function): the minibatch is doubled, row
+// B + i being the mirror image of row i -- column c of the mirrored observation / action is sgn[src] * x[src], src = perm[c]
+// (negate the lateral quantities, then swap the right and left limbs).  Only the kernels that read the rollout arrays
+// through idx know about it: first-layer forward, first-layer weight gradient, loss.
+struct Mirror {
+  const int* obs_perm; const float* obs_sgn;     // [60]
+  const int* act_perm; const float* act_sgn;     // [21]
+  int half;                                      // B: rows >= half are mirrored copies of row - half; 0 = no augmentation
+};
+
 struct FwdJob {            // Y[M][ldy] = act(X[M][ldx] W^T + b); X rows optionally gathered through idx
   const float* X; int ldx;
   const long long* idx;    // null or [M]: row i of X is X[idx[i]]
   const float* W; const float* b; int K, N, act;
   float* Y; int ldy;       // ldy >= N rounded up to 32; columns >= N are written as 0
 };
-struct FwdArgs { FwdJob job[1 + kMaxEns]; int njobs; int M; };
+struct FwdArgs { FwdJob job[1 + kMaxEns]; int njobs; int M; Mirror mir; };
 
 __global__ __launch_bounds__(256) void fwd_layer_kernel(FwdArgs A) {
   __shared__ float red[4][16][64];
@@ -136,13 +146,21 @@ __global__ __launch_bounds__(256) void fwd_layer_kernel(FwdArgs A) {
     if (t >= ntiles) { t -= ntiles; continue; }
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
     const int i = tm * 32 + (lane & 31), j = tn * 32 + (lane & 31), kk = lane >> 5;
-    const long long xi = J.idx ? J.idx[i] : (long long)i;
+    const bool mirrored = J.idx && A.mir.half > 0 && i >= A.mir.half;
+    const long long xi = J.idx ? J.idx[mirrored ? i - A.mir.half : i] : (long long)i;
     const float* xrow = J.X + xi * J.ldx;
     const float* wrow = J.W + (long long)(j < J.N ? j : 0) * J.K;
     const bool jok = j < J.N;
     const int K = J.K;
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto la = [&](int c) { const int k0 = 8 * c + 4 * kk; return (k0 + 3 < K) ? *reinterpret_cast<const float4*>(xrow + k0) : make_float4(0, 0, 0, 0); };
+    auto la = [&](int c) {
+      const int k0 = 8 * c + 4 * kk;
+      if (k0 + 3 >= K) return make_float4(0, 0, 0, 0);
+      if (!mirrored) return *reinterpret_cast<const float4*>(xrow + k0);
+      const int* pm = A.mir.obs_perm + k0;
+      const int s0 = pm[0], s1 = pm[1], s2 = pm[2], s3 = pm[3];
+      return make_float4(A.mir.obs_sgn[s0] * xrow[s0], A.mir.obs_sgn[s1] * xrow[s1], A.mir.obs_sgn[s2] * xrow[s2], A.mir.obs_sgn[s3] * xrow[s3]);
+    };
     auto lb = [&](int c) { const int k0 = 8 * c + 4 * kk; return (jok && k0 + 3 < K) ? *reinterpret_cast<const float4*>(wrow + k0) : make_float4(0, 0, 0, 0); };
     int c0, c1;
     split_range((K + 7) / 8, wave, c0, c1);
@@ -166,7 +184,7 @@ struct BwdJob {            // layer l of one net: delta [M][ldd] (gradient w.r.t
   float* DX; int lddx; int act_prev;   // delta of the previous layer = (D W) * act'(X) -> [M][lddx]; null for the first layer
   float* GW; float* GB;                // slice-0 pointers of dW [N][K] and db [N] inside the partial-gradient buffer
 };
-struct BwdArgs { BwdJob job[1 + kMaxEns]; int njobs; int M; int S; long long slice_stride; };
+struct BwdArgs { BwdJob job[1 + kMaxEns]; int njobs; int M; int S; long long slice_stride; Mirror mir; };
 
 __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdArgs A) {
   __shared__ float red[4][16][64];
@@ -234,10 +252,16 @@ __global__ __launch_bounds__(256) void bwd_layer_kernel(BwdArgs A) {
           const int i = i0 + 8 * c + 4 * kk;
           float4 v;
           if (J.idx) {
-            v.x = kok ? J.X[J.idx[i + 0] * J.ldx + kcol] : 0.f;
-            v.y = kok ? J.X[J.idx[i + 1] * J.ldx + kcol] : 0.f;
-            v.z = kok ? J.X[J.idx[i + 2] * J.ldx + kcol] : 0.f;
-            v.w = kok ? J.X[J.idx[i + 3] * J.ldx + kcol] : 0.f;
+            const int half = A.mir.half;
+            auto gx = [&](int row) {
+              if (!kok) return 0.f;
+              if (half > 0 && row >= half) {
+                const int src = A.mir.obs_perm[kcol];
+                return A.mir.obs_sgn[src] * J.X[J.idx[row - half] * J.ldx + src];
+              }
+              return J.X[J.idx[row] * J.ldx + kcol];
+            };
+            v.x = gx(i + 0); v.y = gx(i + 1); v.z = gx(i + 2); v.w = gx(i + 3);
           } else {
             v.x = kok ? J.X[(long long)(i + 0) * J.ldx + kcol] : 0.f;
             v.y = kok ? J.X[(long long)(i + 1) * J.ldx + kcol] : 0.f;
@@ -293,6 +317,7 @@ struct LossArgs {
   float* dmean; float* dval[kMaxEns];    // output deltas (pre-activation), same shapes as mean / val
   float* part;                           // [M / kLossRows][32]: 0..20 dlogstd, 21 action-loss sum, 22 value-loss sum
   int M, n_ens; float clip; int clipped_value_loss;
+  Mirror mir;
 };
 
 // Half a wavefront (32 lanes) per sample, lane j = column j of the padded 32-wide output rows: every row of the actor's
@@ -310,9 +335,15 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs A) {
   const int per_block = kLossRows;                                                 // samples per block: four per half-wavefront
   const int i_end = min(A.M, (int)(blockIdx.x + 1) * per_block);
   for (int i = blockIdx.x * per_block + half; i < i_end; i += 8) {
-    const long long r = A.idx ? A.idx[i] : (long long)i;
+    const bool mirrored = A.mir.half > 0 && i >= A.mir.half;
+    const long long r = A.idx ? A.idx[mirrored ? i - A.mir.half : i] : (long long)i;
     const float mu = A.mean[(long long)i * A.ldm + j];
-    const float z = jact ? A.act[r * kAct + j] - mu : 0.f;
+    float aj = 0.f;
+    if (jact) {
+      const int src = mirrored ? A.mir.act_perm[j] : j;
+      aj = A.act[r * kAct + src] * (mirrored ? A.mir.act_sgn[src] : 1.f);
+    }
+    const float z = jact ? aj - mu : 0.f;
     float term = jact ? -(z * z) * (0.5f * isd) - ls - 0.9189385332046727f : 0.f;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) term += __shfl_xor(term, off);        // stays inside the 32-lane half
@@ -549,17 +580,19 @@ void ssl_destroy(ssl_learner* L) {
   delete L;
 }
 
-int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
-             const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred, const int64_t* idx,
-             int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss, float* stats_out,
-             void* stream) {
+static int step_impl(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
+                     const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred, const int64_t* idx,
+                     int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss,
+                     float* stats_out, void* stream, const Mirror& mir) {
   if (!L || !params || !adam_m || !adam_v || !lr || !step || !obs || !act || !old_logp || !adv || !ret || !idx)
     return fail(-1, "null argument");
-  if (batch < 32 || batch % 32 || batch > L->max_batch) return fail(-1, "batch must be a multiple of 32 and <= max_batch");
+  const int rows_total = mir.half > 0 ? 2 * batch : batch;
+  if (batch < 32 || batch % 32 || rows_total > L->max_batch)
+    return fail(-1, "batch must be a multiple of 32 and (doubled, with the mirror augmentation) <= max_batch");
   SSL_HIP(hipSetDevice(L->device));
   hipStream_t st = (hipStream_t)stream;
   const Net& N = L->net;
-  const int M = batch, E = N.n_ens;
+  const int M = rows_total, E = N.n_ens;
   // batch slices of the weight-gradient GEMMs (each slice's four wavefronts split it again); every slice must be a multiple
   // of the 8-row MFMA block
   int S = kMaxSplit;                 // measured at M = 1024 .. 4096: 8 slices beat 4 and 2 (150 vs 189 vs 230 us per step at 1024)
@@ -572,6 +605,7 @@ int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const 
     FwdArgs A;
     std::memset(&A, 0, sizeof A);
     A.M = M;
+    A.mir = mir;
     int total = 0;
     auto add = [&](const Layer& Ly, const float* X, int ldx, const long long* ix, float* Y) {
       FwdJob& J = A.job[A.njobs++];
@@ -593,7 +627,7 @@ int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const 
     for (int e = 0; e < E; ++e) { A.val[e] = L->cri_buf[e][kCriticLayers - 1]; A.dval[e] = L->dvout[e]; }
     A.logstd = params + N.logstd_off;
     A.act = act; A.old_logp = old_logp; A.adv = adv; A.ret = ret; A.vpred = vpred; A.idx = idx64;
-    A.dmean = L->dout; A.part = L->lpart; A.M = M; A.n_ens = E; A.clip = clip_param;
+    A.dmean = L->dout; A.part = L->lpart; A.M = M; A.n_ens = E; A.clip = clip_param; A.mir = mir;
     A.clipped_value_loss = (use_clipped_value_loss && vpred) ? 1 : 0;
     hipLaunchKernelGGL(loss_kernel, dim3((M + kLossRows - 1) / kLossRows), dim3(256), 0, st, A);
   }
@@ -601,7 +635,7 @@ int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const 
   for (int l = kActorLayers - 1; l >= 0; --l) {
     BwdArgs A;
     std::memset(&A, 0, sizeof A);
-    A.M = M; A.S = S; A.slice_stride = N.n_params;
+    A.M = M; A.S = S; A.slice_stride = N.n_params; A.mir = mir;
     int total = 0;
     auto add = [&](const Layer& Ly, const float* D, int ldd, const float* X, int ldx, const long long* ix, float* DX, int act_prev) {
       BwdJob& J = A.job[A.njobs++];
@@ -642,6 +676,27 @@ int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const 
   }
   SSL_HIP(hipGetLastError());
   return 0;
+}
+
+int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
+             const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred, const int64_t* idx,
+             int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss, float* stats_out,
+             void* stream) {
+  Mirror none;
+  std::memset(&none, 0, sizeof none);
+  return step_impl(L, params, adam_m, adam_v, lr, step, obs, act, old_logp, adv, ret, vpred, idx, batch, clip_param, max_grad_norm,
+                   adam_eps, use_clipped_value_loss, stats_out, stream, none);
+}
+
+int ssl_step_mirror(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
+                    const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred,
+                    const int64_t* idx, int32_t batch, float clip_param, float max_grad_norm, float adam_eps,
+                    int32_t use_clipped_value_loss, float* stats_out, void* stream, const int32_t* obs_perm, const float* obs_sgn,
+                    const int32_t* act_perm, const float* act_sgn) {
+  if (!obs_perm || !obs_sgn || !act_perm || !act_sgn) return fail(-1, "null mirror table");
+  Mirror m{obs_perm, obs_sgn, act_perm, act_sgn, batch};
+  return step_impl(L, params, adam_m, adam_v, lr, step, obs, act, old_logp, adv, ret, vpred, idx, batch, clip_param, max_grad_norm,
+                   adam_eps, use_clipped_value_loss, stats_out, stream, m);
 }
 
 /* gradient of the last ssl_step (after the slice reduction, before clipping): [n_params] device pointer (tests) */

@@ -1,7 +1,7 @@
 """Fused PPO learner: the minibatch loop body of algorithms/ppo.py:55-100 (evaluate_actions, clipped surrogate + value
 loss, backward, clip_grad_norm_, Adam) as 15 launches of hand-written gfx950 kernels (steppingstone_amd/csrc/
 ss_learner.hip, include/steppingstone_learner.h; exact-f32 MFMA GEMMs) instead of ~90 launches of generic framework
-kernels.  Drop-in for steppingstone_amd.ppo.PPO on a single GPU without the mirror augmentation:
+kernels.  Drop-in for steppingstone_amd.ppo.PPO on a single GPU (the mirror augmentation included):
 
     agent = FusedPPO(actor_critic, ppo_epoch=10, mini_batch_size=1024, lr=3e-4, ...)
     value_loss, action_loss, entropy = agent.update(rollouts)          # same contract as PPO.update
@@ -17,7 +17,7 @@ import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEPPINGSTONE_LEARNER_LIB") or os.path.join(PKG, "lib", "libsslearner.so")
-SYMBOLS = ["ssl_last_error", "ssl_num_params", "ssl_create", "ssl_destroy", "ssl_step", "ssl_debug_grad"]
+SYMBOLS = ["ssl_last_error", "ssl_num_params", "ssl_create", "ssl_destroy", "ssl_step", "ssl_step_mirror", "ssl_debug_grad"]
 OBS, HID, ACT = 60, 256, 21
 
 _lib = None
@@ -41,6 +41,7 @@ def load():
         lib.ssl_destroy.argtypes = [vp]
         lib.ssl_destroy.restype = None
         lib.ssl_step.argtypes = [vp] * 13 + [i32, f32, f32, f32, i32, vp, vp]
+        lib.ssl_step_mirror.argtypes = [vp] * 13 + [i32, f32, f32, f32, i32, vp, vp] + [vp] * 4
         lib.ssl_debug_grad.argtypes = [vp]
         lib.ssl_debug_grad.restype = vp
         _lib = lib
@@ -83,8 +84,6 @@ class FusedPPO:
 
     def __init__(self, ac, clip_param=0.2, ppo_epoch=10, mini_batch_size=1024, value_loss_coef=1.0, entropy_coef=0.0, lr=3e-4,
                  eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None, use_graph=True):
-        if mirror_indices is not None:
-            raise FusedLearnerError("the fused learner does not implement the mirror augmentation: use ppo.PPO")
         if value_loss_coef != 1.0 or entropy_coef != 0.0:
             raise FusedLearnerError("the fused learner implements the reference's defaults value_loss_coef=1, entropy_coef=0")
         if mini_batch_size % 32:
@@ -111,9 +110,22 @@ class FusedPPO:
         self.lr_t = torch.tensor(float(lr), device=dev)
         self.step_t = torch.zeros((), device=dev)
         self.stats = torch.zeros(3, device=dev)
+        # mirror augmentation (common/envs_utils.py:687-740): column c of a mirrored row = sgn[src] * x[src], src = perm[c]
+        self.mirror = None
+        if mirror_indices is not None:
+            neg_o, right_o, left_o, neg_a, right_a, left_a = [torch.as_tensor(i, dtype=torch.long).cpu() for i in mirror_indices]
+
+            def tables(neg, right, left, n):
+                perm, sgn = torch.arange(n), torch.ones(n)
+                perm[right], perm[left] = left.clone(), right.clone()
+                sgn[neg] = -1.0
+                return perm.to(torch.int32).to(dev), sgn.to(dev)
+
+            self.mirror = tables(neg_o, right_o, left_o, OBS) + tables(neg_a, right_a, left_a, ACT)
         h = C.c_void_p()
         with torch.cuda.device(dev):
-            _check(self.lib.ssl_create(C.byref(h), dev.index if dev.index is not None else torch.cuda.current_device(), E, mini_batch_size))
+            _check(self.lib.ssl_create(C.byref(h), dev.index if dev.index is not None else torch.cuda.current_device(), E,
+                                       mini_batch_size * (2 if self.mirror else 1)))
         self.h = h
         self.use_graph = bool(use_graph)
         self._graph, self._static_idx, self._data_ptrs, self._warm = None, None, None, 0
@@ -134,10 +146,13 @@ class FusedPPO:
         obs, act, vpred, ret, logp, adv = data
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         self.step_t.add_(1.0)
-        _check(self.lib.ssl_step(self.h, p(self.flat), p(self.m), p(self.v), p(self.lr_t), p(self.step_t), p(obs), p(act), p(logp),
-                                 p(adv), p(ret), p(vpred), p(idx), int(idx.numel()), float(self.clip_param), float(self.max_grad_norm),
-                                 float(self.eps), 1 if self.use_clipped_value_loss else 0, p(self.stats),
-                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        args = [self.h, p(self.flat), p(self.m), p(self.v), p(self.lr_t), p(self.step_t), p(obs), p(act), p(logp), p(adv), p(ret),
+                p(vpred), p(idx), int(idx.numel()), float(self.clip_param), float(self.max_grad_norm), float(self.eps),
+                1 if self.use_clipped_value_loss else 0, p(self.stats), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)]
+        if self.mirror:
+            _check(self.lib.ssl_step_mirror(*args, *[p(t) for t in self.mirror]))
+        else:
+            _check(self.lib.ssl_step(*args))
         return self.stats
 
     def step_minibatch(self, data, idx):
