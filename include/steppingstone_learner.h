@@ -52,6 +52,21 @@ int ssl_step_mirror(ssl_learner* L, float* params, float* adam_m, float* adam_v,
                     int32_t use_clipped_value_loss, float* stats_out, void* stream, const int32_t* obs_perm, const float* obs_sgn,
                     const int32_t* act_perm, const float* act_sgn);
 
+/* Data-parallel learner (configs[4]: one process per GPU, algorithms/ppo.py's update over every rank's rollout): the step in
+ * two halves with the caller's gradient all-reduce between them.
+ *   ssl_grad : forward, losses, backward and the slice reduction of ONE rank's minibatch; the gradient of its mean loss is
+ *              written to grad_out (device, ssl_num_params floats).  Mirror tables as in ssl_step_mirror, or four NULLs.
+ *   (caller) : one all-reduce (sum) of grad_out over the ranks -- RCCL through torch.distributed in fused_ppo.py.
+ *   ssl_apply: grad *= grad_scale (1 / world size: the mean over ranks = the gradient of the mean loss over the global
+ *              minibatch), clip by the global norm, Adam.  Every rank applies the same step to the same weights.
+ * ssl_grad + ssl_apply(grad_scale = 1) on one rank is ssl_step (the norm's summation order differs: ~1e-7 relative). */
+int ssl_grad(ssl_learner* L, const float* params, const float* obs, const float* act, const float* old_logp, const float* adv,
+             const float* ret, const float* vpred, const int64_t* idx, int32_t batch, float clip_param, int32_t use_clipped_value_loss,
+             float* stats_out, float* grad_out, void* stream, const int32_t* obs_perm, const float* obs_sgn, const int32_t* act_perm,
+             const float* act_sgn);
+int ssl_apply(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, float* grad,
+              float grad_scale, float max_grad_norm, float adam_eps, void* stream);
+
 /* gradient of the last ssl_step (slices reduced, before clipping): device pointer to ssl_num_params floats (tests) */
 const float* ssl_debug_grad(ssl_learner* L);
 

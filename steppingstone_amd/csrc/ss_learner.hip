@@ -438,6 +438,21 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs A) {
   if (threadIdx.x == 0) A.sq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Data-parallel path: the all-reduced gradient comes back from the collective; scale it (1 / world size) and rebuild the
+// per-block sums of squares the Adam kernel's clip coefficient is computed from (same 256-element blocks, fixed order).
+__global__ __launch_bounds__(256) void scale_sq_kernel(float* G, long long n, float scale, float* sq) {
+  __shared__ float red[4];
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f;
+  if (p < n) { g = G[p] * scale; G[p] = g; }
+  float v = g * g;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 struct AdamArgs {
   float* P; const float* G; float* m; float* v; long long n;
   const float* sq; int nsq;
@@ -580,12 +595,12 @@ void ssl_destroy(ssl_learner* L) {
   delete L;
 }
 
-static int step_impl(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
-                     const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred, const int64_t* idx,
-                     int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss,
-                     float* stats_out, void* stream, const Mirror& mir) {
-  if (!L || !params || !adam_m || !adam_v || !lr || !step || !obs || !act || !old_logp || !adv || !ret || !idx)
-    return fail(-1, "null argument");
+// forward, loss, backward, slice reduction: the gradient of the minibatch loss lands in `grad` ([n_params], device), the
+// per-block sums of squares in L->sq, the three loss values in stats_out
+static int grad_impl(ssl_learner* L, const float* params, const float* obs, const float* act, const float* old_logp, const float* adv,
+                     const float* ret, const float* vpred, const int64_t* idx, int32_t batch, float clip_param,
+                     int32_t use_clipped_value_loss, float* stats_out, float* grad, void* stream, const Mirror& mir) {
+  if (!L || !params || !obs || !act || !old_logp || !adv || !ret || !idx || !grad) return fail(-1, "null argument");
   const int rows_total = mir.half > 0 ? 2 * batch : batch;
   if (batch < 32 || batch % 32 || rows_total > L->max_batch)
     return fail(-1, "batch must be a multiple of 32 and (doubled, with the mirror augmentation) <= max_batch");
@@ -664,18 +679,36 @@ static int step_impl(ssl_learner* L, float* params, float* adam_m, float* adam_v
   {
     ReduceArgs A;
     A.gpart = L->gpart; A.slice_stride = N.n_params; A.S = S; A.lpart = L->lpart; A.nlossblocks = (M + kLossRows - 1) / kLossRows;
-    A.logstd_off = N.logstd_off; A.G = L->G; A.n = N.n_params; A.sq = L->sq; A.stats = stats_out ? stats_out : L->stats;
+    A.logstd_off = N.logstd_off; A.G = grad; A.n = N.n_params; A.sq = L->sq; A.stats = stats_out ? stats_out : L->stats;
     A.params = params; A.M = M; A.n_ens = E;
     hipLaunchKernelGGL(reduce_kernel, dim3(nblk + 1), dim3(256), 0, st, A);
   }
-  {
-    AdamArgs A;
-    A.P = params; A.G = L->G; A.m = adam_m; A.v = adam_v; A.n = N.n_params; A.sq = L->sq; A.nsq = nblk + 1; A.lr = lr; A.step = step;
-    A.beta1 = 0.9f; A.beta2 = 0.999f; A.eps = adam_eps; A.max_norm = max_grad_norm;
-    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, A);
-  }
   SSL_HIP(hipGetLastError());
   return 0;
+}
+
+// clip by the global norm (from nsq block sums in L->sq) and one Adam step
+static int apply_impl(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* grad,
+                      int nsq, float max_grad_norm, float adam_eps, void* stream) {
+  if (!L || !params || !adam_m || !adam_v || !lr || !step || !grad) return fail(-1, "null argument");
+  const Net& N = L->net;
+  const int nblk = (int)((N.n_params + 255) / 256);
+  AdamArgs A;
+  A.P = params; A.G = grad; A.m = adam_m; A.v = adam_v; A.n = N.n_params; A.sq = L->sq; A.nsq = nsq; A.lr = lr; A.step = step;
+  A.beta1 = 0.9f; A.beta2 = 0.999f; A.eps = adam_eps; A.max_norm = max_grad_norm;
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, A);
+  SSL_HIP(hipGetLastError());
+  return 0;
+}
+
+static int step_impl(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
+                     const float* act, const float* old_logp, const float* adv, const float* ret, const float* vpred, const int64_t* idx,
+                     int32_t batch, float clip_param, float max_grad_norm, float adam_eps, int32_t use_clipped_value_loss,
+                     float* stats_out, void* stream, const Mirror& mir) {
+  if (!L || !adam_m || !adam_v || !lr || !step) return fail(-1, "null argument");
+  if (int rc = grad_impl(L, params, obs, act, old_logp, adv, ret, vpred, idx, batch, clip_param, use_clipped_value_loss, stats_out,
+                         L->G, stream, mir)) return rc;
+  return apply_impl(L, params, adam_m, adam_v, lr, step, L->G, (int)((L->net.n_params + 255) / 256) + 1, max_grad_norm, adam_eps, stream);
 }
 
 int ssl_step(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, const float* obs,
@@ -697,6 +730,29 @@ int ssl_step_mirror(ssl_learner* L, float* params, float* adam_m, float* adam_v,
   Mirror m{obs_perm, obs_sgn, act_perm, act_sgn, batch};
   return step_impl(L, params, adam_m, adam_v, lr, step, obs, act, old_logp, adv, ret, vpred, idx, batch, clip_param, max_grad_norm,
                    adam_eps, use_clipped_value_loss, stats_out, stream, m);
+}
+
+int ssl_grad(ssl_learner* L, const float* params, const float* obs, const float* act, const float* old_logp, const float* adv,
+             const float* ret, const float* vpred, const int64_t* idx, int32_t batch, float clip_param, int32_t use_clipped_value_loss,
+             float* stats_out, float* grad_out, void* stream, const int32_t* obs_perm, const float* obs_sgn, const int32_t* act_perm,
+             const float* act_sgn) {
+  Mirror m;
+  std::memset(&m, 0, sizeof m);
+  if (obs_perm || obs_sgn || act_perm || act_sgn) {
+    if (!obs_perm || !obs_sgn || !act_perm || !act_sgn) return fail(-1, "the four mirror tables come together (or all null)");
+    m = Mirror{obs_perm, obs_sgn, act_perm, act_sgn, batch};
+  }
+  return grad_impl(L, params, obs, act, old_logp, adv, ret, vpred, idx, batch, clip_param, use_clipped_value_loss, stats_out, grad_out,
+                   stream, m);
+}
+
+int ssl_apply(ssl_learner* L, float* params, float* adam_m, float* adam_v, const float* lr, const float* step, float* grad,
+              float grad_scale, float max_grad_norm, float adam_eps, void* stream) {
+  if (!L || !grad) return fail(-1, "null argument");
+  SSL_HIP(hipSetDevice(L->device));
+  const int nblk = (int)((L->net.n_params + 255) / 256);
+  hipLaunchKernelGGL(scale_sq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, (long long)L->net.n_params, grad_scale, L->sq);
+  return apply_impl(L, params, adam_m, adam_v, lr, step, grad, nblk, max_grad_norm, adam_eps, stream);
 }
 
 /* gradient of the last ssl_step (after the slice reduction, before clipping): [n_params] device pointer (tests) */

@@ -1,7 +1,7 @@
 """Fused PPO learner: the minibatch loop body of algorithms/ppo.py:55-100 (evaluate_actions, clipped surrogate + value
 loss, backward, clip_grad_norm_, Adam) as 15 launches of hand-written gfx950 kernels (steppingstone_amd/csrc/
 ss_learner.hip, include/steppingstone_learner.h; exact-f32 MFMA GEMMs) instead of ~90 launches of generic framework
-kernels.  Drop-in for steppingstone_amd.ppo.PPO on a single GPU (the mirror augmentation included):
+kernels.  Drop-in for steppingstone_amd.ppo.PPO (mirror augmentation and the data-parallel update included):
 
     agent = FusedPPO(actor_critic, ppo_epoch=10, mini_batch_size=1024, lr=3e-4, ...)
     value_loss, action_loss, entropy = agent.update(rollouts)          # same contract as PPO.update
@@ -17,7 +17,8 @@ import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEPPINGSTONE_LEARNER_LIB") or os.path.join(PKG, "lib", "libsslearner.so")
-SYMBOLS = ["ssl_last_error", "ssl_num_params", "ssl_create", "ssl_destroy", "ssl_step", "ssl_step_mirror", "ssl_debug_grad"]
+SYMBOLS = ["ssl_last_error", "ssl_num_params", "ssl_create", "ssl_destroy", "ssl_step", "ssl_step_mirror", "ssl_grad", "ssl_apply",
+           "ssl_debug_grad"]
 OBS, HID, ACT = 60, 256, 21
 
 _lib = None
@@ -42,6 +43,8 @@ def load():
         lib.ssl_destroy.restype = None
         lib.ssl_step.argtypes = [vp] * 13 + [i32, f32, f32, f32, i32, vp, vp]
         lib.ssl_step_mirror.argtypes = [vp] * 13 + [i32, f32, f32, f32, i32, vp, vp] + [vp] * 4
+        lib.ssl_grad.argtypes = [vp] * 9 + [i32, f32, i32, vp, vp, vp] + [vp] * 4
+        lib.ssl_apply.argtypes = [vp] * 7 + [f32, f32, f32, vp]
         lib.ssl_debug_grad.argtypes = [vp]
         lib.ssl_debug_grad.restype = vp
         _lib = lib
@@ -83,7 +86,11 @@ class FusedPPO:
     """Same constructor arguments and update() contract as steppingstone_amd.ppo.PPO (defaults of playground/train.py:72-82)."""
 
     def __init__(self, ac, clip_param=0.2, ppo_epoch=10, mini_batch_size=1024, value_loss_coef=1.0, entropy_coef=0.0, lr=3e-4,
-                 eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None, use_graph=True):
+                 eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None, use_graph=True,
+                 data_parallel=None):
+        """data_parallel: None = follow torch.distributed (world size > 1: every minibatch step is ssl_grad on the rank's own
+        minibatch, ONE all-reduce of the flat gradient, ssl_apply with 1 / world -- the reference's update on the global
+        minibatch); True forces the two-call path on a single rank as well (tests)."""
         if value_loss_coef != 1.0 or entropy_coef != 0.0:
             raise FusedLearnerError("the fused learner implements the reference's defaults value_loss_coef=1, entropy_coef=0")
         if mini_batch_size % 32:
@@ -127,7 +134,11 @@ class FusedPPO:
             _check(self.lib.ssl_create(C.byref(h), dev.index if dev.index is not None else torch.cuda.current_device(), E,
                                        mini_batch_size * (2 if self.mirror else 1)))
         self.h = h
-        self.use_graph = bool(use_graph)
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.data_parallel = (self.world > 1) if data_parallel is None else bool(data_parallel)
+        self.gbuf = torch.zeros(n, device=dev) if self.data_parallel else None
+        self.use_graph = bool(use_graph) and self.world == 1        # the collective is not captured
         self._graph, self._static_idx, self._data_ptrs, self._warm = None, None, None, 0
 
     def __del__(self):
@@ -146,6 +157,18 @@ class FusedPPO:
         obs, act, vpred, ret, logp, adv = data
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         self.step_t.add_(1.0)
+        if self.data_parallel:
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            tabs = [p(t) for t in self.mirror] if self.mirror else [None] * 4
+            _check(self.lib.ssl_grad(self.h, p(self.flat), p(obs), p(act), p(logp), p(adv), p(ret), p(vpred), p(idx), int(idx.numel()),
+                                     float(self.clip_param), 1 if self.use_clipped_value_loss else 0, p(self.stats), p(self.gbuf), st,
+                                     *tabs))
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.gbuf)                  # RCCL, one 1.3 MB message per minibatch step
+            _check(self.lib.ssl_apply(self.h, p(self.flat), p(self.m), p(self.v), p(self.lr_t), p(self.step_t), p(self.gbuf),
+                                      1.0 / self.world, float(self.max_grad_norm), float(self.eps), st))
+            return self.stats
         args = [self.h, p(self.flat), p(self.m), p(self.v), p(self.lr_t), p(self.step_t), p(obs), p(act), p(logp), p(adv), p(ret),
                 p(vpred), p(idx), int(idx.numel()), float(self.clip_param), float(self.max_grad_norm), float(self.eps),
                 1 if self.use_clipped_value_loss else 0, p(self.stats), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)]
@@ -185,8 +208,10 @@ class FusedPPO:
         With use_graph one hipGraph holds a WHOLE epoch (every minibatch step of it reads its slice of a static permutation
         buffer and adds its losses to a device accumulator), so the host launches ppo_epoch graphs per update instead of
         ppo_epoch x num_mini_batch steps."""
+        from .ppo import _global_mean_std
         adv = roll.returns[:-1] - roll.value_preds[:-1]
-        adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+        mean, std = _global_mean_std(adv)                   # over every rank's transitions
+        adv = (adv - mean) / (std + 1e-5)
         T, N = roll.rewards.shape[:2]
         R = T * N
         flat = lambda t, w: t.reshape(R, w).contiguous()   # noqa: E731
@@ -226,6 +251,9 @@ class FusedPPO:
 
     def grad(self):
         """Gradient of the last minibatch step (slices reduced, before clipping) as a flat tensor copy (tests)."""
+        if self.data_parallel:
+            torch.cuda.synchronize(self.device)
+            return self.gbuf.clone()                        # after ssl_apply: scaled by 1 / world
         ptr = self.lib.ssl_debug_grad(self.h)
 
         class _Dev:

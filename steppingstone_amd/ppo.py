@@ -445,8 +445,9 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
       logger           ConsoleCSVLogger-compatible object (steppingstone_amd.csv_logger): log_epoch(dict) per update
       save_dir         `{env}_latest.pt` every update, `{env}_{frames}.pt` every save_every frames, `{env}_best.pt` on a new
                        best mean return (train.py:523-562)
-      learner          "fused": the minibatch step runs in the hand-written MFMA kernels of steppingstone_amd.fused_ppo (one
-                       GPU, minibatch a multiple of 32 that divides the rollout); "torch": autograd +
+      learner          "fused": the minibatch step runs in the hand-written MFMA kernels of steppingstone_amd.fused_ppo (GPU,
+                       minibatch a multiple of 32 that divides the rank's rollout; with several ranks one all-reduce of
+                       the flat gradient sits between its gradient and Adam halves); "torch": autograd +
                        torch.optim.Adam (steppingstone_amd.ppo.PPO); "auto": fused whenever its conditions hold
     use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs.  Episode returns go
     through a device ring of the last num_envs episodes in both modes (EpisodeRing = the reference's deque).
@@ -469,9 +470,9 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
         torch.manual_seed(seed + 7919 * rank)            # decorrelate exploration noise / minibatch order across ranks
     mirror = envs.get_mirror_indices() if use_mirror and hasattr(envs, "get_mirror_indices") else None
     n = envs.num_envs
-    fused_ok = (dev.type == "cuda" and not multi and mini_batch_size % 32 == 0 and (num_steps * n) % mini_batch_size == 0)
+    fused_ok = dev.type == "cuda" and mini_batch_size % 32 == 0 and (num_steps * n) % mini_batch_size == 0
     if learner == "fused" and not fused_ok:
-        raise ValueError("learner='fused' needs one GPU and a minibatch (multiple of 32) dividing the rollout")
+        raise ValueError("learner='fused' needs a GPU and a minibatch (multiple of 32) dividing the rank's rollout")
     if learner == "fused" or (learner == "auto" and fused_ok):
         from .fused_ppo import FusedPPO
         agent = FusedPPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror,

@@ -170,3 +170,64 @@ def test_fused_step_with_mirror_augmentation_matches_torch():
         # zero, its ReLU derivative flips between the two implementations, and that sample's delta differs in critics.1.{0,2,4}
         # (1.3e-3 of the largest gradient; later layers and the other nets agree to 1e-6) -- tools/_dbg history in DESIGN 4.3
         assert float((gf - p.grad).abs().max()) / scale < 2e-4, (name, float((gf - p.grad).abs().max()), scale)
+
+
+def test_fused_data_parallel_halves_equal_the_global_minibatch():
+    """configs[4] (one process per GPU): ssl_grad on each rank's minibatch, the sum of the gradients (what the RCCL all-reduce
+    leaves on every rank), ssl_apply with 1 / world.  Two 'ranks' are played on one GPU: the result must be the torch step
+    (autograd, clip_grad_norm_, Adam) on the concatenated minibatch, and both ranks end with the same weights."""
+    import ctypes as C
+    from steppingstone_amd import fused_ppo, ppo
+    dev = torch.device("cuda:0")
+    R, B, E = 4096, 256, 2
+    torch.manual_seed(4)
+    ref = ppo.ActorCritic(num_ensembles=E).to(dev)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    obs, act, vpred, ret, adv = _batch(R, dev, seed=9)
+    with torch.no_grad():
+        _, logp0, _ = ref.evaluate_actions(obs, act)
+    logp = logp0 + 0.3 * torch.randn_like(logp0)
+    data = tuple(t.contiguous() for t in (obs, act, vpred, ret, logp, adv))
+    perm = torch.randperm(R, device=dev)
+    idx = [perm[:B].contiguous(), perm[B:2 * B].contiguous()]
+    ranks = []
+    for r in range(2):
+        ac = ppo.ActorCritic(num_ensembles=E).to(dev)
+        ac.load_state_dict(ref.state_dict())
+        ranks.append(fused_ppo.FusedPPO(ac, mini_batch_size=B, use_graph=False, data_parallel=True))
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for a, ix in zip(ranks, idx):
+        a.step_t.add_(1.0)
+        fused_ppo._check(a.lib.ssl_grad(a.h, p(a.flat), p(obs), p(act), p(logp), p(adv), p(ret), p(vpred), p(ix), B, 0.2, 0, p(a.stats),
+                                        p(a.gbuf), st, None, None, None, None))
+    total = ranks[0].gbuf + ranks[1].gbuf                    # the all-reduce (sum)
+    for a in ranks:
+        a.gbuf.copy_(total)
+        fused_ppo._check(a.lib.ssl_apply(a.h, p(a.flat), p(a.m), p(a.v), p(a.lr_t), p(a.step_t), p(a.gbuf), 0.5, 2.0, 1e-5, st))
+    torch.cuda.synchronize()
+    assert torch.equal(ranks[0].flat, ranks[1].flat)         # same inputs, deterministic kernels: the replicas stay in step
+    w0 = torch.cat([q.detach().reshape(-1) for q in ref.parameters()]).clone()
+    grads, losses = _torch_reference(ref, data, torch.cat(idx))
+    a = ranks[0]
+    moved = float((torch.cat([q.detach().reshape(-1) for q in ref.parameters()]) - w0).abs().max())
+    assert moved > 1e-5
+    for name, q in ref.named_parameters():
+        off, shape = a.layout[name]
+        n = q.numel()
+        scale = float(grads[name].abs().max()) + 1e-12
+        assert float((a.gbuf[off:off + n].view(shape) - grads[name]).abs().max()) / scale < 2e-4, name   # gbuf now holds the mean
+        assert float((a.flat[off:off + n].view(shape) - q.detach()).abs().max()) < 2e-2 * moved + 1e-7, name
+    # the mean of the two ranks' losses is the loss of the global minibatch
+    s = 0.5 * (ranks[0].stats + ranks[1].stats)
+    assert np.allclose(s.cpu().numpy(), losses, rtol=2e-4, atol=2e-6)
+    # and the forced two-call path on one rank is the one-call step
+    one = ppo.ActorCritic(num_ensembles=E).to(dev); two = ppo.ActorCritic(num_ensembles=E).to(dev)
+    one.load_state_dict(ranks[0].ac.state_dict()); two.load_state_dict(ranks[0].ac.state_dict())
+    a1 = fused_ppo.FusedPPO(one, mini_batch_size=B, use_graph=False)
+    a2 = fused_ppo.FusedPPO(two, mini_batch_size=B, use_graph=False, data_parallel=True)
+    a1.step_minibatch(data, idx[0]); a2.step_minibatch(data, idx[0])
+    torch.cuda.synchronize()
+    assert float((a1.flat - a2.flat).abs().max()) < 1e-7
