@@ -48,7 +48,7 @@ constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist p
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 // helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
 // of the spine+leg chain (8 x 9 floats), the base Cholesky factor (21), and back: the six Lambda_own columns (36)
-constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandFloats = 129;
+constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandFloats = 149;   // Det: Rf 9, pen 4, active, cslot, contact, on_target, sole 3
 constexpr int kHandSlots = (kHandFloats + 3) / 4;  // float4-slots per lane
 constexpr int kHandBase = kLdsSlots * kWave * 4;   // in floats
 constexpr int NH = 12;                 // joints per half
@@ -305,15 +305,14 @@ SSD JRec opaque_rec(const JRec& r) {
   return o;
 }
 struct LamPair { ssf2 a[3], b[3]; };
+// Part A needs the leg records (joints 3..7) only: the T columns and the unit impulses carried from the foot up to the pelvis.
+// Part B needs the spine records and the base factor as well: up the spine, base solve, down to the pelvis (G) and the foot
+// (Lambda_own).  The helper wavefronts run A while the main wavefront is still in the spine and the base solve.
+struct OpCarry { SV2 p; ssf2 ul2[NH]; };
 template <class Model, int CPAIR>
-SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
-  JointCache jc;
+SSD void operator_pair_a(const JointCache& jc_in, const Lds& L, JointCache& jc, OpCarry& oc) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
-#pragma unroll
-  for (int i = 0; i < 15; ++i) { jc.L0.l[i] = jc_in.L0.l[i]; SS_REG(jc.L0.l[i]); }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { jc.L0.di[i] = jc_in.L0.di[i]; SS_REG(jc.L0.di[i]); }
+  for (int k = 3; k < 8; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
   {
     SV2 d;
 #pragma unroll
@@ -329,27 +328,45 @@ SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
     L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
     L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
   }
-  ssf2 ul2[NH];
   SV2 p;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     p.w[m] = ssf2{2 * CPAIR == m ? -1.f : 0.f, 2 * CPAIR + 1 == m ? -1.f : 0.f};
     p.v[m] = ssf2{2 * CPAIR == m + 3 ? -1.f : 0.f, 2 * CPAIR + 1 == m + 3 ? -1.f : 0.f};
   }
-  static_rfor<7, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, ul2, p); });
+  static_rfor<7, 3>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, oc.ul2, p); });
+  oc.p = p;
+}
+template <class Model, int CPAIR>
+SSD LamPair operator_pair_b(const JointCache& jc_in, const Lds& L, JointCache& jc, OpCarry& oc) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { jc.L0.l[i] = jc_in.L0.l[i]; SS_REG(jc.L0.l[i]); }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { jc.L0.di[i] = jc_in.L0.di[i]; SS_REG(jc.L0.di[i]); }
+  SV2 p = oc.p;
+  static_rfor<2, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, oc.ul2, p); });
   SV2 d = chol6_solve_neg_pair(jc.L0, p);
-  static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+  static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, oc.ul2, d); });
   L.q2(kLdsG + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
   L.q2(kLdsG + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
   L.q2(kLdsG + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
   L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
   L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
   L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
-  static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, ul2, d); });
+  static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, oc.ul2, d); });
   LamPair o;
   o.a[0] = ssf2{d.w[0].x, d.w[1].x}; o.a[1] = ssf2{d.w[2].x, d.v[0].x}; o.a[2] = ssf2{d.v[1].x, d.v[2].x};
   o.b[0] = ssf2{d.w[0].y, d.w[1].y}; o.b[1] = ssf2{d.w[2].y, d.v[0].y}; o.b[2] = ssf2{d.v[1].y, d.v[2].y};
   return o;
+}
+template <class Model, int CPAIR>
+SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
+  JointCache jc;
+  OpCarry oc;
+  operator_pair_a<Model, CPAIR>(jc_in, L, jc, oc);
+  return operator_pair_b<Model, CPAIR>(jc_in, L, jc, oc);
 }
 
 // Forward kinematics of spine + own leg and contact detection of the own sole's four corners against the three active
@@ -437,28 +454,72 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
 }
 
 #ifndef SS_HOST_HARNESS
-// Helper wavefront of the small-batch variant: between the two workgroup barriers of a substep it computes the
-// contact operators of its column pairs from the joint records the main wavefront handed over, while the main
-// wavefront runs pass 3, forward kinematics and contact detection.
+// Helper wavefronts of the small-batch variant (one workgroup = main wavefront + HELPERS helpers, four barriers per substep):
+//   #0 state of the substep is in LDS         helper 0: cos / sin of joints 0..7, forward kinematics, contact detection -> LDS
+//   #1 leg joint records are handed over      helper h: operators of column pair h, part A (T, impulses up to the pelvis)
+//   #2 spine records + base factor as well    part B (G, Lambda_own)
+//   #3 operators are in LDS
+// while the main wavefront runs cos / sin, pass 1 and the leg half of pass 2 | the spine and the base solve | pass 3, the foot
+// twist and the Jacobian rows | the PGS and the rest.
 template <class Model, int HELPERS>
 __device__ __forceinline__ void helper_substep(int helper, const Lds& L) {
-  __syncthreads();                                   // #1: joint records are in the hand-off region
-  JointCache jc;
-  static_for<0, 8>([&](auto Kc) {
+  __syncthreads();                                   // #0
+  if (helper == 0) {
+    float q8[8], cs8[8], sn8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q8[k] = L.s(S_Q + k);
+    float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
+    SS_MEMBAR();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ss_sincos(q8[k], sn8[k], cs8[k]);
+    float Rb[3][3];
+    quat_rot(quat, Rb);
+    DetectOut det;
+    FootReport fr;
+    fk_detect<Model>(cs8, sn8, Rb, L, det, fr);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) L.hs(kHandDet + a * 3 + c) = det.Rf[a][c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.hs(kHandDet + 9 + k) = det.pen[k];
+    L.hs(kHandDet + 13) = __builtin_bit_cast(float, det.active);
+    L.hs(kHandDet + 14) = __builtin_bit_cast(float, det.cslot);
+    L.hs(kHandDet + 15) = __builtin_bit_cast(float, fr.contact);
+    L.hs(kHandDet + 16) = __builtin_bit_cast(float, fr.on_target);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L.hs(kHandDet + 17 + i) = fr.sole[i];
+  }
+  __syncthreads();                                   // #1: leg joint records are in the hand-off region
+  JointCache jin, jc;
+  static_for<3, 8>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
-    JRec& r = jc.r[k];
+    JRec& r = jin.r[k];
+    r.cs = L.hs(kHandJc + k * 9 + 0); r.sn = L.hs(kHandJc + k * 9 + 1); r.Dinv = L.hs(kHandJc + k * 9 + 2);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { r.Uw[m] = L.hs(kHandJc + k * 9 + 3 + m); r.Uv[m] = L.hs(kHandJc + k * 9 + 6 + m); }
+  });
+  OpCarry oc[HELPERS == 1 ? 3 : 1];
+  static_for<0, 3>([&](auto Cc) {
+    constexpr int c = decltype(Cc)::value;
+    if (HELPERS == 1 || helper == c) operator_pair_a<Model, c>(jin, L, jc, oc[HELPERS == 1 ? c : 0]);
+  });
+  __syncthreads();                                   // #2: spine records and the base factor
+  static_for<0, 3>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    JRec& r = jin.r[k];
     r.cs = L.hs(kHandJc + k * 9 + 0); r.sn = L.hs(kHandJc + k * 9 + 1); r.Dinv = L.hs(kHandJc + k * 9 + 2);
 #pragma unroll
     for (int m = 0; m < 3; ++m) { r.Uw[m] = L.hs(kHandJc + k * 9 + 3 + m); r.Uv[m] = L.hs(kHandJc + k * 9 + 6 + m); }
   });
 #pragma unroll
-  for (int i = 0; i < 15; ++i) jc.L0.l[i] = L.hs(kHandL0 + i);
+  for (int i = 0; i < 15; ++i) jin.L0.l[i] = L.hs(kHandL0 + i);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) jc.L0.di[i] = L.hs(kHandL0 + 15 + i);
+  for (int i = 0; i < 6; ++i) jin.L0.di[i] = L.hs(kHandL0 + 15 + i);
   static_for<0, 3>([&](auto Cc) {
     constexpr int c = decltype(Cc)::value;
     if (HELPERS == 1 || helper == c) {
-      const LamPair lp = operator_pair<Model, c>(jc, L);
+      const LamPair lp = operator_pair_b<Model, c>(jin, L, jc, oc[HELPERS == 1 ? c : 0]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         L.hs(kHandLc + (2 * c) * 6 + 2 * i) = lp.a[i].x; L.hs(kHandLc + (2 * c) * 6 + 2 * i + 1) = lp.a[i].y;
@@ -466,7 +527,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L) {
       }
     }
   });
-  __syncthreads();                                   // #2: G, T and Lambda_own are ready
+  __syncthreads();                                   // #3: G, T and Lambda_own are ready
 }
 #endif
 
@@ -476,6 +537,9 @@ template <class Model, int HELPERS = 0>
 SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (HELPERS > 0) __syncthreads();        // #0: the state of this substep is in LDS (helper 0: kinematics + detection)
+#endif
   SS_PROF(0);
   // LDS round trips (~100 cycles) are fully exposed with one wavefront per SIMD, and the compiler issues each
   // ds_read right before its use: batch the loads of a phase up front / prefetch one joint ahead instead.
@@ -669,6 +733,22 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         I2 = Ipn;
         p2 = ppn;
       });
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (HELPERS > 0) {     // leg joint records to the helper wavefront(s): operators, part A
+        static_for<3, 8>([&](auto Kc) {
+          constexpr int k = decltype(Kc)::value;
+          const JRec& r = jc.r[k];
+          L.hs(kHandJc + k * 9 + 0) = r.cs; L.hs(kHandJc + k * 9 + 1) = r.sn; L.hs(kHandJc + k * 9 + 2) = r.Dinv;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) { L.hs(kHandJc + k * 9 + 3 + m) = r.Uw[m]; L.hs(kHandJc + k * 9 + 6 + m) = r.Uv[m]; }
+        });
+        // the machine scheduler would otherwise pull the spine and the base solve in front of the barrier (it orders memory
+        // operations only), and the helpers' part A would overlap nothing
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();               // #1
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       // I2 / p2: leg half in pelvis coordinates, arm half in torso coordinates.  Add the partner lane's limbs
       // (mirrored), commutative (mine + partner) so that both lanes get bit-identical totals.
       ABI Il = abi_half(I2, 0), Ia = abi_half(I2, 1);
@@ -723,8 +803,8 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     }
     SS_PROF(4);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (HELPERS > 0) {       // hand the spine+leg joint records and the base factor to the helper wavefront(s)
-      static_for<0, 8>([&](auto Kc) {
+    if constexpr (HELPERS > 0) {       // spine joint records and the base factor: operators, part B
+      static_for<0, 3>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         const JRec& r = jc.r[k];
         L.hs(kHandJc + k * 9 + 0) = r.cs; L.hs(kHandJc + k * 9 + 1) = r.sn; L.hs(kHandJc + k * 9 + 2) = r.Dinv;
@@ -735,7 +815,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int m = 0; m < 15; ++m) L.hs(kHandL0 + m) = jc.L0.l[m];
 #pragma unroll
       for (int m = 0; m < 6; ++m) L.hs(kHandL0 + 15 + m) = jc.L0.di[m];
-      __syncthreads();                 // #1
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                 // #2
+      __builtin_amdgcn_sched_barrier(0);
     }
 #endif
     // ---- pass 3: accelerations -> free velocities
@@ -797,7 +879,20 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   // ---- detect: FK of spine + own leg, own sole corners vs stones.  (Round 2 measured this on helper 0, overlapped with
   // pass 2: the main wavefront then waits for the operators at barrier #2 instead -- 0.0685 vs 0.0654 ms/step; rejected.)
   DetectOut det;
-  {
+  if constexpr (HELPERS > 0) {         // helper 0 did it between barriers #0 and #1
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) det.Rf[a][c] = L.hs(kHandDet + a * 3 + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) det.pen[k] = L.hs(kHandDet + 9 + k);
+    det.active = __builtin_bit_cast(int, L.hs(kHandDet + 13));
+    det.cslot = __builtin_bit_cast(int, L.hs(kHandDet + 14));
+    fr.contact = __builtin_bit_cast(int, L.hs(kHandDet + 15));
+    fr.on_target = __builtin_bit_cast(int, L.hs(kHandDet + 16));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fr.sole[i] = L.hs(kHandDet + 17 + i);
+  } else {
     float cs8[8], sn8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { cs8[k] = jc.r[k].cs; sn8[k] = jc.r[k].sn; }
@@ -812,52 +907,32 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   for (int k = 0; k < NH; ++k) dqd[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dv0.w[i] = 0.f; dv0.v[i] = 0.f; }
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (HELPERS > 0) __syncthreads();   // #2: the helper wavefront(s) have written G, T and Lambda_own
-#endif
   const int active = det.active, cslot = det.cslot;
   const float (&Rf)[3][3] = det.Rf;
   const float (&pen)[4] = det.pen;
   const int pair_active = active | xchg_i(active);   // both lanes must take the contact branch together
 #ifdef SS_ABLATE_CONTACT
-  if (false) {
+  const bool in_contact = false;
 #else
-  if (pair_active != 0) {
+  const bool in_contact = pair_active != 0;
 #endif
-    const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    float ul[NH];
-    ssf2 Lc[6][3];                     // column b of Lambda_own as three pairs
-    if constexpr (HELPERS > 0) {
+  ssf2 Lc[6][3];                       // column b of Lambda_own as three pairs
+  SS_PROF(7);
+  // What does not need the contact operators: with helper wavefronts it overlaps part B of their work.
+  float V[6];                          // own-foot twist under the free velocities
+  ssf2 rWp[12][3];                     // Jacobian row w = (c x dir, dir) per (corner, direction), as three float pairs
+  float rB[4];
+  auto rows_free = [&]() {          // V and the Jacobian rows: nothing here reads the operators
+      {
+        SV a = v0f;
+        static_for<0, 8>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          a = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, a);
+          a.w[kAxis[j]] += SS_QDF(j);
+        });
 #pragma unroll
-      for (int b = 0; b < 6; ++b)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Lc[b][i] = pkv(L.hs(kHandLc + b * 6 + 2 * i), L.hs(kHandLc + b * 6 + 2 * i + 1));
-    } else {
-      static_for<0, 3>([&](auto Cc) {
-        constexpr int c = decltype(Cc)::value;
-        const LamPair lp = operator_pair<Model, c>(jc, L);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { Lc[2 * c][i] = lp.a[i]; Lc[2 * c + 1][i] = lp.b[i]; }
-      });
-    }
-    SS_PROF(7);
-    // own-foot twist under the free velocities
-    float V[6];
-    {
-      SV a = v0f;
-      static_for<0, 8>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        a = xmotion<Model, j>(jc.r[j].cs, jc.r[j].sn, a);
-        a.w[kAxis[j]] += SS_QDF(j);
-      });
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
-    }
-    // rows (registers, float pairs): per (corner, direction) y = Lambda_own w and the Jacobian row w = (c x dir, dir),
-    // 1/A, b_n.  Inactive corners keep finite rows (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
-    ssf2 rYp[12][3], rWp[12][3];
-    float rIA[12], rB[4];
-    {
+        for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
+      }
       static_for<0, 4>([&](auto Kc) {
         constexpr int k = decltype(Kc)::value;
         constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
@@ -882,118 +957,156 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           w[0] = cy * w[5] - cz * w[4];
           w[1] = cz * w[3] - cx * w[5];
           w[2] = cx * w[4] - cy * w[3];
-          ssf2 y[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) y[i] = Lc[0][i] * ssf2{w[0], w[0]};
-#pragma unroll
-          for (int b = 1; b < 6; ++b)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) y[i] = Lc[b][i] * ssf2{w[b], w[b]} + y[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { rYp[row][i] = y[i]; rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]}; }
-          ssf2 acc = rWp[row][0] * y[0];
-          acc = rWp[row][1] * y[1] + acc;
-          acc = rWp[row][2] * y[2] + acc;
-          rIA[row] = on ? SS_RCP(acc.x + acc.y) : 0.f;
+          for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
         });
       });
-    }
-    SS_PROF(8);
-    // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
-    // the rows y = Lambda w and w, the sweep's wrench and the G / T columns are held as three float pairs each
-    float lam[4][3];
+  };
+  auto solve = [&]() {              // y = Lambda w, PGS, response of the whole tree
+      const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      float ul[NH];
+      if constexpr (HELPERS > 0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lam[k][0] = lam[k][1] = lam[k][2] = 0.f;
-    constexpr float mu = Model::friction;
-    ssf2 Vp[3] = {{V[0], V[1]}, {V[2], V[3]}, {V[4], V[5]}};
-    ssf2 Wp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    ssf2 dWp[3];
-    auto sweep = [&]() {           // Gauss-Seidel over the own foot's 12 rows
+        for (int b = 0; b < 6; ++b)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) dWp[i] = ssf2{0.f, 0.f};
+          for (int i = 0; i < 3; ++i) Lc[b][i] = pkv(L.hs(kHandLc + b * 6 + 2 * i), L.hs(kHandLc + b * 6 + 2 * i + 1));
+      }
+      // rows (registers, float pairs): per (corner, direction) y = Lambda_own w, 1/A.  Inactive corners keep finite rows
+      // (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
+      ssf2 rYp[12][3];
+      float rIA[12];
       static_for<0, 12>([&](auto Rc) {
-        constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
-        ssf2 acc = rWp[row][0] * Vp[0];
-        acc = rWp[row][1] * Vp[1] + acc;
-        acc = rWp[row][2] * Vp[2] + acc;
-        float vrel = acc.x + acc.y;
-        float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
-        if constexpr (d == 0) {
-          ln = fmaxf(ln, 0.f);
-        } else {
-          float lim = mu * lam[k][0];
-          ln = fminf(fmaxf(ln, -lim), lim);
-        }
-        const float dl = ln - lam[k][d];
-        lam[k][d] = ln;
-        const ssf2 dl2 = {dl, dl};
+        constexpr int row = decltype(Rc)::value, k = row / 3;
+        const bool on = (active >> k) & 1;
+        const float w[6] = {rWp[row][0].x, rWp[row][0].y, rWp[row][1].x, rWp[row][1].y, rWp[row][2].x, rWp[row][2].y};
+        ssf2 y[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { Vp[i] = rYp[row][i] * dl2 + Vp[i]; dWp[i] = rWp[row][i] * dl2 + dWp[i]; }
+        for (int i = 0; i < 3; ++i) y[i] = Lc[0][i] * ssf2{w[0], w[0]};
+#pragma unroll
+        for (int b = 1; b < 6; ++b)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) y[i] = Lc[b][i] * ssf2{w[b], w[b]} + y[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rYp[row][i] = y[i];
+        ssf2 acc = rWp[row][0] * y[0];
+        acc = rWp[row][1] * y[1] + acc;
+        acc = rWp[row][2] * y[2] + acc;
+        rIA[row] = on ? SS_RCP(acc.x + acc.y) : 0.f;
       });
+      SS_PROF(8);
+      // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
+      // the rows y = Lambda w and w, the sweep's wrench and the G / T columns are held as three float pairs each
+      float lam[4][3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) Wp[i] += dWp[i];
-    };
+      for (int k = 0; k < 4; ++k) lam[k][0] = lam[k][1] = lam[k][2] = 0.f;
+      constexpr float mu = Model::friction;
+      ssf2 Vp[3] = {{V[0], V[1]}, {V[2], V[3]}, {V[4], V[5]}};
+      ssf2 Wp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      ssf2 dWp[3];
+      auto sweep = [&]() {           // Gauss-Seidel over the own foot's 12 rows
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dWp[i] = ssf2{0.f, 0.f};
+        static_for<0, 12>([&](auto Rc) {
+          constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
+          ssf2 acc = rWp[row][0] * Vp[0];
+          acc = rWp[row][1] * Vp[1] + acc;
+          acc = rWp[row][2] * Vp[2] + acc;
+          float vrel = acc.x + acc.y;
+          float ln = lam[k][d] + ((d == 0 ? rB[k] : 0.f) - vrel) * rIA[row];
+          if constexpr (d == 0) {
+            ln = fmaxf(ln, 0.f);
+          } else {
+            float lim = mu * lam[k][0];
+            ln = fminf(fmaxf(ln, -lim), lim);
+          }
+          const float dl = ln - lam[k][d];
+          lam[k][d] = ln;
+          const ssf2 dl2 = {dl, dl};
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { Vp[i] = rYp[row][i] * dl2 + Vp[i]; dWp[i] = rWp[row][i] * dl2 + dWp[i]; }
+        });
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Wp[i] += dWp[i];
+      };
 #ifdef SS_PGS_NO_PEEL
-    constexpr int kCoupled = kPgsIters;
+      constexpr int kCoupled = kPgsIters;
 #else
-    constexpr int kCoupled = kPgsIters - 1;   // after the last sweep nothing reads the foot twist any more: its coupling is dead
+      constexpr int kCoupled = kPgsIters - 1;   // after the last sweep nothing reads the foot twist any more: its coupling is dead
 #endif
 #pragma unroll 1
-    for (int it = 0; it < kCoupled; ++it) {
-      sweep();
-      // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
-      // this foot through T
-      ssf2 dpp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      for (int it = 0; it < kCoupled; ++it) {
+        sweep();
+        // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
+        // this foot through T
+        ssf2 dpp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int l = 0; l < 6; ++l) {
-        const float sc = (l & 1) ? dWp[l >> 1].y : dWp[l >> 1].x;
-        const ssf2 s2 = {sc, sc};
+        for (int l = 0; l < 6; ++l) {
+          const float sc = (l & 1) ? dWp[l >> 1].y : dWp[l >> 1].x;
+          const ssf2 s2 = {sc, sc};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float2 c = L.q2(kLdsG + l * 3 + i);
-          dpp[i] = ssf2{c.x, c.y} * s2 + dpp[i];
+          for (int i = 0; i < 3; ++i) {
+            const float2 c = L.q2(kLdsG + l * 3 + i);
+            dpp[i] = ssf2{c.x, c.y} * s2 + dpp[i];
+          }
+        }
+        SV dp = {{dpp[0].x, dpp[0].y, dpp[1].x}, {dpp[1].y, dpp[2].x, dpp[2].y}};
+        const SV dpo = xchg_sv(dp);
+        const float dpv[6] = {dpo.w[0], dpo.w[1], dpo.w[2], dpo.v[0], dpo.v[1], dpo.v[2]};
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+          const ssf2 s2 = {dpv[l], dpv[l]};
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float2 c = L.q2(kLdsT + l * 3 + i);
+            Vp[i] = ssf2{c.x, c.y} * s2 + Vp[i];
+          }
         }
       }
-      SV dp = {{dpp[0].x, dpp[0].y, dpp[1].x}, {dpp[1].y, dpp[2].x, dpp[2].y}};
-      const SV dpo = xchg_sv(dp);
-      const float dpv[6] = {dpo.w[0], dpo.w[1], dpo.w[2], dpo.v[0], dpo.v[1], dpo.v[2]};
-#pragma unroll
-      for (int l = 0; l < 6; ++l) {
-        const ssf2 s2 = {dpv[l], dpv[l]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float2 c = L.q2(kLdsT + l * 3 + i);
-          Vp[i] = ssf2{c.x, c.y} * s2 + Vp[i];
-        }
-      }
-    }
 #ifndef SS_PGS_NO_PEEL
-    sweep();
+      sweep();
 #endif
-    SV W = {{Wp[0].x, Wp[0].y, Wp[1].x}, {Wp[1].y, Wp[2].x, Wp[2].y}};
-    SS_PROF(9);
-    // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down
+      SV W = {{Wp[0].x, Wp[0].y, Wp[1].x}, {Wp[1].y, Wp[2].x, Wp[2].y}};
+      SS_PROF(9);
+      // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down
 #ifndef SS_ABLATE_FINAL
-    {
-      SV p = {{-W.w[0], -W.w[1], -W.w[2]}, {-W.v[0], -W.v[1], -W.v[2]}};
-      static_rfor<7, 3>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
-      const SV po = xchg_sv(p);
+      {
+        SV p = {{-W.w[0], -W.w[1], -W.w[2]}, {-W.v[0], -W.v[1], -W.v[2]}};
+        static_rfor<7, 3>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
+        const SV po = xchg_sv(p);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { p.w[i] += po.w[i]; p.v[i] += po.v[i]; }
-      static_rfor<2, 0>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
-      dv0 = chol6_solve_neg(jc.L0, p);
-      SV d = dv0;
-      static_for<0, 8>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        d = imp_down<Model, j, true>(jc, ul, d, &dqd[half_pos(j)]);
-      });
-      d = dv0;
-      static_for<13, 17>([&](auto Jc) {
-        constexpr int j = decltype(Jc)::value;
-        d = imp_down<Model, j, false>(jc, ul, d, &dqd[half_pos(j)]);
-      });
-    }
+        for (int i = 0; i < 3; ++i) { p.w[i] += po.w[i]; p.v[i] += po.v[i]; }
+        static_rfor<2, 0>([&](auto Jc) { p = imp_up<Model, decltype(Jc)::value>(jc, ul, p); });
+        dv0 = chol6_solve_neg(jc.L0, p);
+        SV d = dv0;
+        static_for<0, 8>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          d = imp_down<Model, j, true>(jc, ul, d, &dqd[half_pos(j)]);
+        });
+        d = dv0;
+        static_for<13, 17>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          d = imp_down<Model, j, false>(jc, ul, d, &dqd[half_pos(j)]);
+        });
+      }
 #endif
+  };
+  if constexpr (HELPERS == 0) {     // one block, the operators first (before the rows occupy the registers)
+    if (in_contact) {
+      static_for<0, 3>([&](auto Cc) {
+        constexpr int c = decltype(Cc)::value;
+        const LamPair lp = operator_pair<Model, c>(jc, L);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Lc[2 * c][i] = lp.a[i]; Lc[2 * c + 1][i] = lp.b[i]; }
+      });
+      rows_free();
+      solve();
+    }
+  } else {
+    if (in_contact) rows_free();
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();                 // #3: the helper wavefront(s) have written G, T and Lambda_own
+#endif
+    if (in_contact) solve();
   }
   SS_MEMBAR();
   SS_PROF(10);
