@@ -48,8 +48,9 @@ constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist p
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 // helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
 // of the spine+leg chain (8 x 9 floats), the base Cholesky factor (21), and back: the six Lambda_own columns (36)
-constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandFloats = 149;   // Det: Rf 9, pen 4, active, cslot, contact, on_target, sole 3
+constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandAct = 146, kHandFloats = 158, kHandCs = kHandLc;   // Det: Rf 9, pen 4, flags (active | cslot << 4 | contact << 12 | on_target << 13), sole 3; Act: the next step's 12 actions (rollout kernel); Cs: cos[12], sin[12] of the joint angles, aliasing Lc (dead between barriers #0 and #2)
 constexpr int kHandSlots = (kHandFloats + 3) / 4;  // float4-slots per lane
+static_assert(kLdsSlots + kHandSlots <= 80, "two helper-variant workgroups must fit the 160 KiB of a CU (16384 envs: 512 workgroups)");
 constexpr int kHandBase = kLdsSlots * kWave * 4;   // in floats
 constexpr int NH = 12;                 // joints per half
 enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_QDF = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
@@ -84,6 +85,14 @@ struct Prof { int unused; };
 #define SS_PROF_ARG
 #define SS_PROF(i) ((void)0)
 #endif
+
+// cos / sin of the joint angles on the helper wavefronts (and the joint torques ahead of them on the main one) from this many
+// helpers on.  Measured: with three helpers 0.0598 -> 0.0581 ms/step at 4096 envs; a single helper that also evaluates the 12
+// cos / sin is slower than leaving them on the main wavefront (16384 envs, rollout kernel: 0.0631 vs 0.0608 ms/step).
+#ifndef SS_CS_OFFLOAD_MIN
+#define SS_CS_OFFLOAD_MIN 3
+#endif
+constexpr bool cs_offload(int helpers) { return helpers >= SS_CS_OFFLOAD_MIN; }
 
 struct Lds {       // lane-private view of the workgroup's LDS
   float* base;
@@ -454,24 +463,49 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
 }
 
 #ifndef SS_HOST_HARNESS
-// Helper wavefronts of the small-batch variant (one workgroup = main wavefront + HELPERS helpers, four barriers per substep):
-//   #0 state of the substep is in LDS         helper 0: cos / sin of joints 0..7, forward kinematics, contact detection -> LDS
+// Helper wavefronts of the small-batch variant (one workgroup = main wavefront + HELPERS helpers, five barriers per substep):
+//   #0 state of the substep is in LDS         helpers 1, 2: cos / sin of the joint angles -> LDS (main: joint torques)
+//   #0b                                        helper 0: forward kinematics, contact detection -> LDS
 //   #1 leg joint records are handed over      helper h: operators of column pair h, part A (T, impulses up to the pelvis)
 //   #2 spine records + base factor as well    part B (G, Lambda_own)
 //   #3 operators are in LDS
 // while the main wavefront runs cos / sin, pass 1 and the leg half of pass 2 | the spine and the base solve | pass 3, the foot
 // twist and the Jacobian rows | the PGS and the rest.
-template <class Model, int HELPERS>
-__device__ __forceinline__ void helper_substep(int helper, const Lds& L) {
+// `extra` is run by the last helper between #0 and #1, where helpers other than 0 are idle (the rollout kernel draws the next
+// step's actions there).
+template <class Model, int HELPERS, class Extra>
+__device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&& extra) {
   __syncthreads();                                   // #0
+  if constexpr (cs_offload(HELPERS)) {   // cos / sin of the 12 joint angles for everybody: helpers 1 and 2 take six each
+    constexpr int kPer = HELPERS >= 3 ? 6 : NH;
+    const int first = HELPERS >= 3 ? (helper - 1) * 6 : 0;
+    if (HELPERS < 3 || helper >= 1) {
+      float qh[kPer], c_[kPer], s_[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) qh[k] = L.s(S_Q + first + k);
+      SS_MEMBAR();
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) ss_sincos(qh[k], s_[k], c_[k]);
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) { L.hs(kHandCs + first + k) = c_[k]; L.hs(kHandCs + NH + first + k) = s_[k]; }
+    }
+    __syncthreads();                                 // #0b
+  }
   if (helper == 0) {
-    float q8[8], cs8[8], sn8[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) q8[k] = L.s(S_Q + k);
+    float cs8[8], sn8[8];
     float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
-    SS_MEMBAR();
+    if constexpr (cs_offload(HELPERS)) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ss_sincos(q8[k], sn8[k], cs8[k]);
+      for (int k = 0; k < 8; ++k) { cs8[k] = L.hs(kHandCs + k); sn8[k] = L.hs(kHandCs + NH + k); }
+      SS_MEMBAR();
+    } else {
+      float q8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q8[k] = L.s(S_Q + k);
+      SS_MEMBAR();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss_sincos(q8[k], sn8[k], cs8[k]);
+    }
     float Rb[3][3];
     quat_rot(quat, Rb);
     DetectOut det;
@@ -483,13 +517,12 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L) {
       for (int c = 0; c < 3; ++c) L.hs(kHandDet + a * 3 + c) = det.Rf[a][c];
 #pragma unroll
     for (int k = 0; k < 4; ++k) L.hs(kHandDet + 9 + k) = det.pen[k];
-    L.hs(kHandDet + 13) = __builtin_bit_cast(float, det.active);
-    L.hs(kHandDet + 14) = __builtin_bit_cast(float, det.cslot);
-    L.hs(kHandDet + 15) = __builtin_bit_cast(float, fr.contact);
-    L.hs(kHandDet + 16) = __builtin_bit_cast(float, fr.on_target);
+    const int flags = det.active | (det.cslot << 4) | (fr.contact << 12) | (fr.on_target << 13);
+    L.hs(kHandDet + 13) = __builtin_bit_cast(float, flags);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) L.hs(kHandDet + 17 + i) = fr.sole[i];
+    for (int i = 0; i < 3; ++i) L.hs(kHandDet + 14 + i) = fr.sole[i];
   }
+  if (helper == HELPERS - 1) extra();
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
   JointCache jin, jc;
   static_for<3, 8>([&](auto Kc) {
@@ -546,15 +579,45 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   float qdfr[NH];              // free joint velocities
 #define SS_QDF(k) qdfr[k]
   float qd_all[NH], q_all[NH], act_all[NH];
-  {
 #pragma unroll
-    for (int k = 0; k < NH; ++k) { q_all[k] = L.s(S_Q + k); qd_all[k] = L.s(S_QD + k); act_all[k] = L.s(S_ACT + k); }
+  for (int k = 0; k < NH; ++k) { q_all[k] = L.s(S_Q + k); qd_all[k] = L.s(S_QD + k); act_all[k] = L.s(S_ACT + k); }
+  SS_MEMBAR();
+  // explicit joint torque and implicit diagonal of joint j (PHYSICS.md 3.1)
+  auto joint_tau = [&](auto Jc, float q, float qd, float act, float& tau, float& Dadd) {
+    constexpr int j = decltype(Jc)::value;
+    constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
+    constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j], tq = Model::torque[j];
+    float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
+    bool lim = viol != 0.f;
+    float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
+    tau = power * tq * act - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
+    Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
+  };
+  float tau_pre[NH], dadd_pre[NH];     // helper variant: the joint torques here, while the helpers evaluate cos / sin
+  if constexpr (cs_offload(HELPERS) && HELPERS > 0) {
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value;
+      joint_tau(std::integral_constant<int, kHalf[k]>{}, q_all[k], qd_all[k], act_all[k], tau_pre[k], dadd_pre[k]);
+    });
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                   // #0b: cos / sin are in the hand-off region
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int k = 0; k < NH; ++k) { jc.r[k].cs = L.hs(kHandCs + k); jc.r[k].sn = L.hs(kHandCs + NH + k); }
     SS_MEMBAR();
+  } else {
     static_for<0, NH>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       ss_sincos(q_all[k], jc.r[k].sn, jc.r[k].cs);
     });
   }
+  auto tau_of = [&](auto Jc, auto Kc, float& tau, float& Dadd) {
+    constexpr int k = decltype(Kc)::value;
+    if constexpr (cs_offload(HELPERS) && HELPERS > 0) { tau = tau_pre[k]; Dadd = dadd_pre[k]; }
+    else joint_tau(Jc, q_all[k], qd_all[k], act_all[k], tau, Dadd);
+  };
   SS_PROF(1);
 
   // ================= leg joints 3..6 and arm joints 13..16 as float pairs {leg, arm} (ss_pair.hpp) =================
@@ -596,26 +659,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     }
     SS_PROF(2);
     // ---- pass 2: articulated inertias, leaves -> root
-#define SS_QS(k) q_all[k]
-#define SS_AS(k) act_all[k]
-    // explicit joint torque and implicit diagonal of joint j (PHYSICS.md 3.1)
-    auto joint_tau = [&](auto Jc, float q, float qd, float act, float& tau, float& Dadd) {
-      constexpr int j = decltype(Jc)::value;
-      constexpr float lo = Model::lo[j], hi = Model::hi[j], kd = Model::damping[j], ks = Model::stiffness[j];
-      constexpr float klim = Model::klim[j], dlim = Model::dlim[j], arm = Model::armature[j], tq = Model::torque[j];
-      float viol = q > hi ? q - hi : (q < lo ? q - lo : 0.f);
-      bool lim = viol != 0.f;
-      float kl = lim ? klim : 0.f, dl = lim ? dlim : 0.f;
-      tau = power * tq * act - kd * qd - ks * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
-      Dadd = arm + h * (kd + dl) + (h * h) * (ks + kl);
-    };
     // one scalar joint: consumes the articulated inertia / bias of its child body, leaves the joint record, returns the
     // contribution to the parent (parent coordinates)
     auto joint_scalar = [&](auto Jc, ABI I, const SV& pA, const SV& vb, ABI& Ip, SV& pp) {
       constexpr int j = decltype(Jc)::value, k = half_pos(j), ax = kAxis[j];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       float tau, Dadd;
-      joint_tau(Jc, SS_QS(k), qd_all[k], SS_AS(k), tau, Dadd);
+      tau_of(Jc, std::integral_constant<int, k>{}, tau, Dadd);
       const float qd = qd_all[k];
       JRec& r = jc.r[k];
       r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
@@ -657,8 +707,8 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       constexpr int i = decltype(Ic)::value, jl = 3 + i, ja = 13 + i, kl = 3 + i, ka = 8 + i, ax = kAxis[jl];
       constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       float taul, Daddl, taua, Dadda;
-      joint_tau(std::integral_constant<int, jl>{}, SS_QS(kl), qd_all[kl], SS_AS(kl), taul, Daddl);
-      joint_tau(std::integral_constant<int, ja>{}, SS_QS(ka), qd_all[ka], SS_AS(ka), taua, Dadda);
+      tau_of(std::integral_constant<int, jl>{}, std::integral_constant<int, kl>{}, taul, Daddl);
+      tau_of(std::integral_constant<int, ja>{}, std::integral_constant<int, ka>{}, taua, Dadda);
       const ssf2 qd = qd2[i];
       const SV2& vb = vp[i];
       JRec2& r = jr2[i];
@@ -886,12 +936,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int c = 0; c < 3; ++c) det.Rf[a][c] = L.hs(kHandDet + a * 3 + c);
 #pragma unroll
     for (int k = 0; k < 4; ++k) det.pen[k] = L.hs(kHandDet + 9 + k);
-    det.active = __builtin_bit_cast(int, L.hs(kHandDet + 13));
-    det.cslot = __builtin_bit_cast(int, L.hs(kHandDet + 14));
-    fr.contact = __builtin_bit_cast(int, L.hs(kHandDet + 15));
-    fr.on_target = __builtin_bit_cast(int, L.hs(kHandDet + 16));
+    const int flags = __builtin_bit_cast(int, L.hs(kHandDet + 13));
+    det.active = flags & 15;
+    det.cslot = (flags >> 4) & 255;
+    fr.contact = (flags >> 12) & 1;
+    fr.on_target = (flags >> 13) & 1;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fr.sole[i] = L.hs(kHandDet + 17 + i);
+    for (int i = 0; i < 3; ++i) fr.sole[i] = L.hs(kHandDet + 14 + i);
   } else {
     float cs8[8], sn8[8];
 #pragma unroll

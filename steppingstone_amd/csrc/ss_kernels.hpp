@@ -326,6 +326,22 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
   return fminf(fmaxf(q, lo), hi);
 }
 
+// Benchmark actions of control step tt for this lane's half of env e (PHYSICS.md 5: six Philox blocks per env and step, 21 of the
+// 24 words -> U(-1,1)), in the lane's own (mirrored) world.
+template <class Write>
+SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t tt, Write&& write) {
+  uint32_t ra[6][4];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+    const float sg = mirror_flips(jr) ? m : 1.f;
+    const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
+    write(k, sg * (2.f * u01(bits) - 1.f));
+  });
+}
+
 // One control step, lane `lane_global` = 2*env + side (side 0: right half, true world; side 1: left half, mirrored
 // world).  PHYSICS.md section 4.  Env-level logic runs redundantly (and identically) in both lanes in the true world.
 // ROLLOUT: io.nsteps control steps in ONE launch (actions from the benchmark Philox stream at io.t, io.t+1, ...): the
@@ -397,27 +413,26 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
 #pragma unroll 1
   for (int kstep = 0; kstep < nsteps; ++kstep) {
   // clipped actions of this lane's joints (its own world) into LDS
-  {
-    uint32_t ra[6][4];
-    if constexpr (RANDOM_ACT) {
-      const uint32_t tt = (uint32_t)io.t + (uint32_t)kstep;
+  if constexpr (RANDOM_ACT) {
+    bool drawn = false;
+    if constexpr (ROLLOUT && HELPERS > 1) {   // (a single helper is the critical path already: 0.0612 vs 0.0638 ms/step at 16384 envs)
+      if (kstep > 0) {               // the last helper wavefront drew them during the previous step (rollout_kernel_helped)
+        float a[NH];
 #pragma unroll
-      for (int b = 0; b < 6; ++b)
-        philox4x32_10(6u * tt + b, 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
+        for (int k = 0; k < NH; ++k) a[k] = L.hs(kHandAct + k);
+#pragma unroll
+        for (int k = 0; k < NH; ++k) L.s(S_ACT + k) = a[k];
+        drawn = true;
+      }
     }
+    if (!drawn) random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep, [&](int k, float a) { L.s(S_ACT + k) = a; });
+  } else {
     static_for<0, NH>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value, jr = kHalf[k];
-      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
       const float sg = mirror_flips(jr) ? m : 1.f;
-      float a;
-      if constexpr (RANDOM_ACT) {
-        const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
-        a = 2.f * u01(bits) - 1.f;
-      } else {
-        const float x = ain[k];
-        a = fminf(fmaxf(x, -1.f), 1.f);
-        a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
-      }
+      const float x = ain[k];
+      float a = fminf(fmaxf(x, -1.f), 1.f);
+      a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8
       L.s(S_ACT + k) = sg * a;
     });
   }
@@ -792,7 +807,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
   } else {
     const Lds L{lds, lane};
 #pragma unroll 1
-    for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L);
+    for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L, [] {});
   }
 }
 // K control steps per launch (ss_rollout_random): same code, state resident in LDS between the steps
@@ -810,9 +825,18 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
     step_env<Model, true, HELPERS, true>(P, io, blockIdx.x * kWave + lane, lane, lds);
   } else {
     const Lds L{lds, lane};
-    const int nsub = io.nsteps * SS_NUM_SUBSTEPS;
+    const int lane_global = blockIdx.x * kWave + lane, side = lane_global & 1;
+    const int e = min(lane_global >> 1, P.n - 1);
+    const float m = side ? -1.f : 1.f;
 #pragma unroll 1
-    for (int k = 0; k < nsub; ++k) helper_substep<Model, HELPERS>(wave - 1, L);
+    for (int kstep = 0; kstep < io.nsteps; ++kstep)
+#pragma unroll 1
+      for (int k = 0; k < SS_NUM_SUBSTEPS; ++k)
+        helper_substep<Model, HELPERS>(wave - 1, L, [&] {
+          // the next control step's actions, while the main wavefront is in pass 1 / 2 of this step's first substep
+          if (HELPERS > 1 && k == 0 && kstep + 1 < io.nsteps)
+            random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
+        });
   }
 }
 #endif  // SS_HOST_HARNESS
