@@ -48,9 +48,16 @@ constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist p
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 // helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
 // of the spine+leg chain (8 x 9 floats), the base Cholesky factor (21), and back: the six Lambda_own columns (36)
-constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandAct = 146, kHandFloats = 158, kHandCs = kHandLc;   // Det: Rf 9, pen 4, flags (active | cslot << 4 | contact << 12 | on_target << 13), sole 3; Act: the next step's 12 actions (rollout kernel); Cs: cos[12], sin[12] of the joint angles, aliasing Lc (dead between barriers #0 and #2)
+constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandAct = 146, kHandFloats = 158, kHandCs = kHandLc;   // Det: Rf 9, pen 4 (single-helper variant only), flags (active | cslot << 4 | contact << 12 | on_target << 13), sole 3; Act: the next step's 12 actions (rollout kernel); Cs: cos[12], sin[12] of the joint angles, aliasing Lc (dead between barriers #0 and #2)
+// The directions of the 12 contact rows (36 floats) and the 4 Baumgarte terms, computed by helper 0: they take the place of the
+// leg joint records once every helper has loaded those (written after barrier #2, read by the main wavefront after #3).
+constexpr int kHandRows = kHandJc + 3 * 9;
+// ... with three helpers; a single helper is the critical path in its windows already (16384 envs: 0.0676 vs 0.0609 ms/step)
+constexpr bool rows_offload(int helpers) { return helpers >= 3; }
 constexpr int kHandSlots = (kHandFloats + 3) / 4;  // float4-slots per lane
+// (a larger hand-off region is not free: 81 KiB per workgroup cost 6 us per launch, 99 KiB 14 us -- measured)
 static_assert(kLdsSlots + kHandSlots <= 80, "two helper-variant workgroups must fit the 160 KiB of a CU (16384 envs: 512 workgroups)");
+static_assert(kHandRows + 40 <= kHandJc + 8 * 9, "rows fit the leg records' place");
 constexpr int kHandBase = kLdsSlots * kWave * 4;   // in floats
 constexpr int NH = 12;                 // joints per half
 enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_QDF = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
@@ -462,6 +469,49 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
   o.cslot = cslot;
 }
 
+// Jacobian rows of the own foot's four sole corners: per (corner k, direction d = normal, t1, t2) the row w = (c x dir, dir) in
+// foot coordinates as three float pairs, and the Baumgarte term of the normal row (PHYSICS.md 3.4).  Inactive corners get finite
+// rows (normal +z).
+// moment part of a row: c x dir for sole corner K (w[3..5] = dir in foot coordinates)
+template <class Model, int K>
+SSD void row_moment(float (&w)[6]) {
+  constexpr float cx = Model::corners[K][0], cy = Model::corners[K][1], cz = Model::corners[K][2];
+  w[0] = cy * w[5] - cz * w[4];
+  w[1] = cz * w[3] - cx * w[5];
+  w[2] = cx * w[4] - cy * w[3];
+}
+template <class Model>
+SSD void jacobian_rows(const DetectOut& det, const Lds& L, ssf2 (&rWp)[12][3], float (&rB)[4]) {
+  const int active = det.active, cslot = det.cslot;
+  const float (&Rf)[3][3] = det.Rf;
+  const float (&pen)[4] = det.pen;
+  static_for<0, 4>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value;
+    const bool on = (active >> k) & 1;
+    const int sl = (cslot >> (2 * k)) & 3;
+    float n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) n[i] = on ? L.s(S_STN + sl * 3 + i) : (i == 2 ? 1.f : 0.f);
+    float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
+    float t2[3];
+    cross(n, t1, t2);
+    float corr = fmaxf(pen[k] - kSlop, 0.f);
+    rB[k] = on ? fminf(kErp * corr * (1.0f / kH), kVcorrMax) : 0.f;
+    static_for<0, 3>([&](auto Dc) {
+      constexpr int d = decltype(Dc)::value, row = k * 3 + d;
+      const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
+      float w[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) w[3 + c] = Rf[0][c] * dir[0] + Rf[1][c] * dir[1] + Rf[2][c] * dir[2];
+      row_moment<Model, k>(w);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
+    });
+  });
+}
+
 #ifndef SS_HOST_HARNESS
 // Helper wavefronts of the small-batch variant (one workgroup = main wavefront + HELPERS helpers, five barriers per substep):
 //   #0 state of the substep is in LDS         helpers 1, 2: cos / sin of the joint angles -> LDS (main: joint torques)
@@ -491,6 +541,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     }
     __syncthreads();                                 // #0b
   }
+  float rowdir[12][3], rowB[4];       // helper 0: directions of the contact rows, Baumgarte terms
   if (helper == 0) {
     float cs8[8], sn8[8];
     float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
@@ -511,16 +562,23 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     DetectOut det;
     FootReport fr;
     fk_detect<Model>(cs8, sn8, Rb, L, det, fr);
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) L.hs(kHandDet + a * 3 + c) = det.Rf[a][c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) L.hs(kHandDet + 9 + k) = det.pen[k];
     const int flags = det.active | (det.cslot << 4) | (fr.contact << 12) | (fr.on_target << 13);
     L.hs(kHandDet + 13) = __builtin_bit_cast(float, flags);
 #pragma unroll
     for (int i = 0; i < 3; ++i) L.hs(kHandDet + 14 + i) = fr.sole[i];
+    if constexpr (!rows_offload(HELPERS)) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) L.hs(kHandDet + a * 3 + c) = det.Rf[a][c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) L.hs(kHandDet + 9 + k) = det.pen[k];
+    } else {                           // the rows' directions stay in registers until the leg records' place is free (after #2)
+      ssf2 rWp[12][3];
+      jacobian_rows<Model>(det, L, rWp, rowB);
+#pragma unroll
+      for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
+    }
   }
   if (helper == HELPERS - 1) extra();
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
@@ -538,6 +596,14 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     if (HELPERS == 1 || helper == c) operator_pair_a<Model, c>(jin, L, jc, oc[HELPERS == 1 ? c : 0]);
   });
   __syncthreads();                                   // #2: spine records and the base factor
+  if (rows_offload(HELPERS) && helper == 0) {
+#pragma unroll
+    for (int row = 0; row < 12; ++row)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) L.hs(kHandRows + row * 3 + i) = rowdir[row][i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.hs(kHandRows + 36 + k) = rowB[k];
+  }
   static_for<0, 3>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
     JRec& r = jin.r[k];
@@ -930,12 +996,14 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   // pass 2: the main wavefront then waits for the operators at barrier #2 instead -- 0.0685 vs 0.0654 ms/step; rejected.)
   DetectOut det;
   if constexpr (HELPERS > 0) {         // helper 0 did it between barriers #0 and #1
+    if constexpr (!rows_offload(HELPERS)) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) det.Rf[a][c] = L.hs(kHandDet + a * 3 + c);
+        for (int c = 0; c < 3; ++c) det.Rf[a][c] = L.hs(kHandDet + a * 3 + c);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) det.pen[k] = L.hs(kHandDet + 9 + k);
+      for (int k = 0; k < 4; ++k) det.pen[k] = L.hs(kHandDet + 9 + k);
+    }
     const int flags = __builtin_bit_cast(int, L.hs(kHandDet + 13));
     det.active = flags & 15;
     det.cslot = (flags >> 4) & 255;
@@ -958,9 +1026,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   for (int k = 0; k < NH; ++k) dqd[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dv0.w[i] = 0.f; dv0.v[i] = 0.f; }
-  const int active = det.active, cslot = det.cslot;
-  const float (&Rf)[3][3] = det.Rf;
-  const float (&pen)[4] = det.pen;
+  const int active = det.active;
   const int pair_active = active | xchg_i(active);   // both lanes must take the contact branch together
 #ifdef SS_ABLATE_CONTACT
   const bool in_contact = false;
@@ -984,34 +1050,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
       }
-      static_for<0, 4>([&](auto Kc) {
-        constexpr int k = decltype(Kc)::value;
-        constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
-        const bool on = (active >> k) & 1;
-        const int sl = (cslot >> (2 * k)) & 3;
-        float n[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) n[i] = on ? L.s(S_STN + sl * 3 + i) : (i == 2 ? 1.f : 0.f);
-        float t1[3] = {1.f - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
-        float inv = SS_RSQRT(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
-        t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
-        float t2[3];
-        cross(n, t1, t2);
-        float corr = fmaxf(pen[k] - kSlop, 0.f);
-        rB[k] = on ? fminf(kErp * corr * (1.0f / kH), kVcorrMax) : 0.f;
-        static_for<0, 3>([&](auto Dc) {
-          constexpr int d = decltype(Dc)::value, row = k * 3 + d;
-          const float* dir = d == 0 ? n : (d == 1 ? t1 : t2);
-          float w[6];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) w[3 + c] = Rf[0][c] * dir[0] + Rf[1][c] * dir[1] + Rf[2][c] * dir[2];
-          w[0] = cy * w[5] - cz * w[4];
-          w[1] = cz * w[3] - cx * w[5];
-          w[2] = cx * w[4] - cy * w[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
-        });
-      });
+      if constexpr (!rows_offload(HELPERS)) jacobian_rows<Model>(det, L, rWp, rB);
   };
   auto solve = [&]() {              // y = Lambda w, PGS, response of the whole tree
       const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -1021,6 +1060,20 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         for (int b = 0; b < 6; ++b)
 #pragma unroll
           for (int i = 0; i < 3; ++i) Lc[b][i] = pkv(L.hs(kHandLc + b * 6 + 2 * i), L.hs(kHandLc + b * 6 + 2 * i + 1));
+      }
+      if constexpr (rows_offload(HELPERS)) {
+        // the rows' directions and Baumgarte terms from helper 0 (written after barrier #2); the moment part here
+        static_for<0, 12>([&](auto Rc) {
+          constexpr int row = decltype(Rc)::value;
+          float w[6];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) w[3 + i] = L.hs(kHandRows + row * 3 + i);
+          row_moment<Model, row / 3>(w);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
+        });
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rB[k] = L.hs(kHandRows + 36 + k);
       }
       // rows (registers, float pairs): per (corner, direction) y = Lambda_own w, 1/A.  Inactive corners keep finite rows
       // (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
