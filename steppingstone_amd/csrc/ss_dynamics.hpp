@@ -521,8 +521,8 @@ SSD void jacobian_rows(const DetectOut& det, const Lds& L, ssf2 (&rWp)[12][3], f
 //   #3 operators are in LDS
 // while the main wavefront runs cos / sin, pass 1 and the leg half of pass 2 | the spine and the base solve | pass 3, the foot
 // twist and the Jacobian rows | the PGS and the rest.
-// `extra` is run by the last helper between #0 and #1, where helpers other than 0 are idle (the rollout kernel draws the next
-// step's actions there).
+// `extra(helper)` runs between #0b and #1, where helpers 1 and 2 are idle: the rollout kernel draws the next step's actions there
+// (last helper) and emits the previous step's outputs (helper 1, three-helper variant).
 template <class Model, int HELPERS, class Extra>
 __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&& extra) {
   __syncthreads();                                   // #0
@@ -580,7 +580,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
       for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
     }
   }
-  if (helper == HELPERS - 1) extra();
+  extra(helper);
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
   JointCache jin, jc;
   static_for<3, 8>([&](auto Kc) {

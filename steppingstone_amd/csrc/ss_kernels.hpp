@@ -326,6 +326,215 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
   return fminf(fmaxf(q, lo), hi);
 }
 
+// ---- output stage of a control step: observation / reward / done / info rows and the bulk of the state write-back ----
+struct StepOut {        // what it needs, true world, after the optional reset
+  float pos[3], quat[4];
+  SV v0;
+  float qt[NH], qdt[NH];                      // this lane's joints
+  float r, z_init, roll, pitch, cyaw, syaw;   // roll .. syaw: of the orientation the step ended in (not used after a reset)
+  int d, flags, do_reset;
+  float tgt[2][5];                            // stones n and n+1: centre (3), tilts (2)
+  ss_info inf;
+};
+// Observation / info rows are staged in LDS (region A is free at that point) and written out by the whole wavefront as
+// contiguous 256-byte stores: a lane writing its own [60]-float row directly would touch 32 partial cache lines
+// per store instruction (measured 3.1x the algorithmic HBM traffic before this).  The host harness runs lanes one
+// after the other, so it keeps the direct writes.
+template <class Model, bool ROLLOUT>
+SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e, int side, bool valid, int lane, int lane_global,
+                      int kstep, float* lds) {
+  const size_t np = (size_t)P.npad;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Rows are staged back to back in the layout of the output block -- [32][60] for obs, [32][62] = obs | rew | done for the
+  // packed block -- so that the wavefront copies the block with float4 loads / stores (8 iterations instead of 31 scalar
+  // ones with an index division each; the 4-way bank conflicts of the stride-60 staging writes are fire-and-forget).
+  constexpr int kPackW = SS_OBS_DIM + 2;
+  const bool packed_layout = io.packed != nullptr || io.peers != nullptr;   // wavefront-uniform
+  const int stride = packed_layout ? kPackW : SS_OBS_DIM;
+  constexpr int kInfoBase = kEnvsPerWave * 64;         // behind the largest staged block
+  float* stage = lds + (lane >> 1) * stride;
+  uint32_t* istage = reinterpret_cast<uint32_t*>(lds) + kInfoBase + (lane >> 1) * 5;
+#define SS_OBS(i) stage[i]
+#else
+  float* op_direct = io.obs + (size_t)e * SS_OBS_DIM;
+#define SS_OBS(i) op_direct[i]
+#endif
+  if (valid) {
+    float* Fo = P.fstate + e;
+    // per-joint state + observation entries: own limbs by each lane, spine by the right lane
+    static_for<0, NH>([&](auto Kc) {
+      constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
+      const int gj = side ? jl : jr;
+      if (jr >= 3 || side == 0) {
+        // normalisation with the TRUE joint's range: a mirrored x/z joint has range (-hi, -lo)
+        constexpr float midr = 0.5f * (Model::lo[jr] + Model::hi[jr]);
+        constexpr float span = Model::hi[jr] - Model::lo[jr];
+        const float mid = (side && mirror_flips(jr)) ? -midr : midr;
+        Fo[(F_Q + gj) * np] = o.qt[k];
+        Fo[(F_QD + gj) * np] = o.qdt[k];
+        SS_OBS(6 + gj) = clip5(2.f * (o.qt[k] - mid) / span);
+        SS_OBS(27 + gj) = clip5(0.1f * o.qdt[k]);
+      }
+    });
+    if (side == 0) {
+      float R[3][3];
+      quat_rot(o.quat, R);
+      float vw[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vw[i] = R[i][0] * o.v0.v[0] + R[i][1] * o.v0.v[1] + R[i][2] * o.v0.v[2];
+      // a reset leaves the identity orientation: roll = pitch = yaw = 0 exactly; otherwise the values of the final orientation
+      const float r2 = o.do_reset ? 0.f : o.roll, p2 = o.do_reset ? 0.f : o.pitch;
+      const float cy = o.do_reset ? 1.f : o.cyaw, sy = o.do_reset ? 0.f : o.syaw;
+      SS_OBS(0) = clip5(o.pos[2] - o.z_init);
+      SS_OBS(1) = clip5(cy * vw[0] + sy * vw[1]);
+      SS_OBS(2) = clip5(-sy * vw[0] + cy * vw[1]);
+      SS_OBS(3) = clip5(vw[2]);
+      SS_OBS(4) = clip5(r2);
+      SS_OBS(5) = clip5(p2);
+      SS_OBS(48) = (o.flags & 1) ? 1.f : 0.f;
+      SS_OBS(49) = (o.flags & 2) ? 1.f : 0.f;
+      float t[5];
+      target_features(o.pos, cy, sy, &o.tgt[0][0], &o.tgt[0][3], t);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) SS_OBS(50 + i) = t[i];
+      target_features(o.pos, cy, sy, &o.tgt[1][0], &o.tgt[1][3], t);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) SS_OBS(55 + i) = t[i];
+      if (io.rew) io.rew[e] = o.r;
+      if (io.done) io.done[e] = o.d ? 1 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (packed_layout) {
+        stage[SS_OBS_DIM] = o.r;
+        stage[SS_OBS_DIM + 1] = o.d ? 1.f : 0.f;
+      }
+      istage[0] = SS_F2U(o.inf.ep_ret); istage[1] = SS_F2U(o.inf.ep_len);
+      istage[2] = (uint32_t)o.inf.bad_transition; istage[3] = (uint32_t)o.inf.steps_reached; istage[4] = (uint32_t)o.inf.update_terrain;
+#else
+      if (io.info) io.info[e] = o.inf;
+      if (io.packed) {
+        float* pk = io.packed + (size_t)e * (SS_OBS_DIM + 2);
+        for (int i = 0; i < SS_OBS_DIM; ++i) pk[i] = op_direct[i];
+        pk[SS_OBS_DIM] = o.r;
+        pk[SS_OBS_DIM + 1] = o.d ? 1.f : 0.f;
+      }
+#endif
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Fo[(F_POS + i) * np] = o.pos[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Fo[(F_QUAT + i) * np] = o.quat[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { Fo[(F_VEL + i) * np] = o.v0.w[i]; Fo[(F_VEL + 3 + i) * np] = o.v0.v[i]; }
+    }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    SS_MEMBAR();
+    const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
+    const int nvalid = min(kEnvsPerWave, P.n - env0);
+    // copy the staged block (nfl floats from the start of the LDS staging area) to dst: float4 when dst is 16-byte aligned
+    auto copy_block = [&](float* dst, int nfl) {
+      if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int n4 = nfl >> 2;
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float4* s4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll 1
+        for (int g = lane; g < n4; g += kWave) d4[g] = s4[g];
+        for (int g = (n4 << 2) + lane; g < nfl; g += kWave) dst[g] = lds[g];
+      } else {
+#pragma unroll 1
+        for (int g = lane; g < nfl; g += kWave) dst[g] = lds[g];
+      }
+    };
+    if (io.obs) {
+      float* og = io.obs + (size_t)env0 * SS_OBS_DIM;
+      if (!packed_layout) {
+        copy_block(og, nvalid * SS_OBS_DIM);
+      } else {                                   // both outputs requested: the staging has the packed layout
+#pragma unroll 1
+        for (int g = lane; g < nvalid * SS_OBS_DIM; g += kWave) {
+          const int el = g / SS_OBS_DIM, idx = g - el * SS_OBS_DIM;
+          og[g] = lds[el * kPackW + idx];
+        }
+      }
+    }
+    if (io.packed) {
+      float* pk = io.packed + (size_t)env0 * kPackW;
+      if constexpr (ROLLOUT) pk += (long long)kstep * io.packed_step_stride;
+      copy_block(pk, nvalid * kPackW);
+    }
+    if (io.info) {
+      uint32_t* ig = reinterpret_cast<uint32_t*>(io.info + env0);
+      const uint32_t* is = reinterpret_cast<const uint32_t*>(lds) + kInfoBase;
+      for (int g = lane; g < nvalid * 5; g += kWave) ig[g] = is[g];
+    }
+    if constexpr (!ROLLOUT) {
+      if (io.peers) {
+        constexpr int kPack = SS_OBS_DIM + 2;
+        const PeerTable* T = io.peers;
+        const int G = T->count;
+        const size_t row0 = (size_t)T->rank * (size_t)T->n_local + (size_t)env0;
+#pragma unroll 1
+        for (int p = 0; p < G; ++p) copy_block(T->dst[p] + row0 * kPack, nvalid * kPack);
+        __threadfence_system();                                   // my rows are visible to every agent ...
+        if (lane == 0) {
+          const uint32_t prev = atomicAdd(T->done_counter, 1u);   // ... before I count myself
+          if ((prev + 1u) % gridDim.x == 0u) {                    // last workgroup of this launch (launches are stream-ordered)
+            __threadfence_system();
+            for (int p = 0; p < G; ++p)
+              __hip_atomic_store(T->flag[p] + T->rank, io.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+    }
+  }
+#endif
+#undef SS_OBS
+}
+
+// The three-helper rollout kernel hands the output stage to helper 1: the main wavefront leaves 14 words in the hand-off region (the
+// place of the detection's Rf / pen, which that variant does not use, and the two spare words), everything else is the state in
+// LDS region B (refreshed after a reset).  Helper 1 works while the main wavefront is already in the next
+// control step (between barriers #0b and #1 of its first substep; the state in LDS changes at that substep's end only).
+constexpr bool out_offload(int helpers, bool rollout) { return rollout && helpers >= 3; }   // (one launch per step: 0.0697 vs 0.0687 ms inline)
+constexpr int kHandOut = kHandDet, kHandOut2 = kHandFloats;     // 13 + 2 words
+static_assert(kHandOut2 + 2 <= kHandSlots * 4, "hand-off region");
+#if !defined(SS_HOST_HARNESS)
+template <class Model, bool ROLLOUT>
+__device__ __forceinline__ void emit_from_handoff(const Params& P, const StepIO& io, const Lds& L, int lane, int lane_global, int kstep,
+                                                  float* lds) {
+  const int e_raw = lane_global >> 1, side = lane_global & 1;
+  const bool valid = e_raw < P.n;
+  const int e = valid ? e_raw : P.n - 1;
+  const float m = side ? -1.f : 1.f;
+  StepOut o;
+  o.pos[0] = L.s(S_POS); o.pos[1] = m * L.s(S_POS + 1); o.pos[2] = L.s(S_POS + 2);
+  o.quat[0] = L.s(S_QUAT); o.quat[1] = m * L.s(S_QUAT + 1); o.quat[2] = L.s(S_QUAT + 2); o.quat[3] = m * L.s(S_QUAT + 3);
+  o.v0 = SV{{m * L.s(S_VW), L.s(S_VW + 1), m * L.s(S_VW + 2)}, {L.s(S_VV), m * L.s(S_VV + 1), L.s(S_VV + 2)}};
+  static_for<0, NH>([&](auto Kc) {
+    constexpr int k = decltype(Kc)::value, jr = kHalf[k];
+    const float sg = mirror_flips(jr) ? m : 1.f;
+    o.qt[k] = sg * L.s(S_Q + k);
+    o.qdt[k] = sg * L.s(S_QD + k);
+  });
+  o.r = L.hs(kHandOut + 0);
+  o.z_init = L.hs(kHandOut + 1);
+  o.inf.ep_ret = L.hs(kHandOut + 2);
+  const int bits = __builtin_bit_cast(int, L.hs(kHandOut2 + 0));
+  o.d = bits & 1;
+  o.inf.bad_transition = (bits >> 1) & 1;
+  o.inf.update_terrain = (bits >> 2) & 1;
+  o.do_reset = (bits >> 3) & 1;
+  o.flags = (bits >> 4) & 3;
+  o.inf.steps_reached = (bits >> 8) & 31;
+  o.inf.ep_len = (float)((bits >> 16) & 0xffff);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { o.tgt[0][i] = L.hs(kHandOut + 3 + i); o.tgt[1][i] = L.hs(kHandOut + 8 + i); }
+  quat_roll_pitch_cs(o.quat, o.roll, o.pitch, o.cyaw, o.syaw);      // same function, same bits as the main wavefront's
+  emit_outputs<Model, ROLLOUT>(P, io, o, e, side, valid, lane, lane_global, kstep, lds);
+}
+#endif
+
 // Benchmark actions of control step tt for this lane's half of env e (PHYSICS.md 5: six Philox blocks per env and step, 21 of the
 // 24 words -> U(-1,1)), in the lane's own (mirrored) world.
 template <class Write>
@@ -351,6 +560,12 @@ SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t
 template <class Model, bool RANDOM_ACT, int HELPERS = 0, bool ROLLOUT = false>
 SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, float* lds) {
   static_assert(!ROLLOUT || RANDOM_ACT, "a multi-step launch draws its actions on the device");
+  constexpr bool kOffload =            // output stage on helper 1
+#if defined(__HIP_DEVICE_COMPILE__)
+      out_offload(HELPERS, ROLLOUT);
+#else
+      false;
+#endif
   const int e_raw = lane_global >> 1, side = lane_global & 1;
   const bool valid = e_raw < P.n;
   int e = valid ? e_raw : P.n - 1;
@@ -454,7 +669,8 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   F = P.fstate + e;
   const Knobs K = *P.knobs;                     // wavefront-uniform scalar loads
   Cache c;                                      // true world
-  load_cache(P, e, c);
+  load_cache(P, e, c);                          // (keeping these 32 words resident in LDS between the steps of the rollout kernel was
+  // measured slower, 0.0556 vs 0.0539 ms/step: the loads' latency is covered by the arithmetic below already)
   float pot_prev = F[F_POT * np], z_init = F[F_ZINIT * np];
   float ep_ret = F[F_EPRET * np], nn_dr = F[F_NNDR * np];
   int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
@@ -597,168 +813,9 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       qdt[k] = sg * L.s(S_QD + k);
     }
   });
-  // Observation / info rows are staged in LDS (region A is free now) and written out by the whole wavefront as
-  // contiguous 256-byte stores: a lane writing its own [60]-float row directly would touch 32 partial cache lines
-  // per store instruction (measured 3.1x the algorithmic HBM traffic before this).  The host harness runs lanes one
-  // after the other, so it keeps the direct writes.
-#if defined(__HIP_DEVICE_COMPILE__)
-  // Rows are staged back to back in the layout of the output block -- [32][60] for obs, [32][62] = obs | rew | done for the
-  // packed block -- so that the wavefront copies the block with float4 loads / stores (8 iterations instead of 31 scalar
-  // ones with an index division each; the 4-way bank conflicts of the stride-60 staging writes are fire-and-forget).
-  constexpr int kPackW = SS_OBS_DIM + 2;
-  const bool packed_layout = io.packed != nullptr || io.peers != nullptr;   // wavefront-uniform
-  const int stride = packed_layout ? kPackW : SS_OBS_DIM;
-  constexpr int kInfoBase = kEnvsPerWave * 64;         // behind the largest staged block
-  float* stage = lds + (lane >> 1) * stride;
-  uint32_t* istage = reinterpret_cast<uint32_t*>(lds) + kInfoBase + (lane >> 1) * 5;
-#define SS_OBS(i) stage[i]
-#else
-  float* op_direct = io.obs + (size_t)e * SS_OBS_DIM;
-#define SS_OBS(i) op_direct[i]
-#endif
-  if (valid) {
-    float* Fo = P.fstate + e;
-    // per-joint state + observation entries: own limbs by each lane, spine by the right lane
-    static_for<0, NH>([&](auto Kc) {
-      constexpr int k = decltype(Kc)::value, jr = kHalf[k];
-      constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
-      const int gj = side ? jl : jr;
-      if (jr >= 3 || side == 0) {
-        // normalisation with the TRUE joint's range: a mirrored x/z joint has range (-hi, -lo)
-        constexpr float midr = 0.5f * (Model::lo[jr] + Model::hi[jr]);
-        constexpr float span = Model::hi[jr] - Model::lo[jr];
-        const float mid = (side && mirror_flips(jr)) ? -midr : midr;
-        Fo[(F_Q + gj) * np] = qt[k];
-        Fo[(F_QD + gj) * np] = qdt[k];
-        SS_OBS(6 + gj) = clip5(2.f * (qt[k] - mid) / span);
-        SS_OBS(27 + gj) = clip5(0.1f * qdt[k]);
-      }
-    });
-    if (side == 0) {
-      float R[3][3];
-      quat_rot(quat, R);
-      float vw[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) vw[i] = R[i][0] * v0.v[0] + R[i][1] * v0.v[1] + R[i][2] * v0.v[2];
-      // a reset leaves the identity orientation: roll = pitch = yaw = 0 exactly; otherwise the values computed above
-      const float r2 = do_reset ? 0.f : roll, p2 = do_reset ? 0.f : pitch;
-      const float cy = do_reset ? 1.f : cyaw, sy = do_reset ? 0.f : syaw;
-      SS_OBS(0) = clip5(pos[2] - z_init);
-      SS_OBS(1) = clip5(cy * vw[0] + sy * vw[1]);
-      SS_OBS(2) = clip5(-sy * vw[0] + cy * vw[1]);
-      SS_OBS(3) = clip5(vw[2]);
-      SS_OBS(4) = clip5(r2);
-      SS_OBS(5) = clip5(p2);
-      SS_OBS(48) = (flags & 1) ? 1.f : 0.f;
-      SS_OBS(49) = (flags & 2) ? 1.f : 0.f;
-      float t[5];
-      target_features(pos, cy, sy, c.p[1], c.tilt[1], t);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) SS_OBS(50 + i) = t[i];
-      target_features(pos, cy, sy, c.p[2], c.tilt[2], t);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) SS_OBS(55 + i) = t[i];
-      if (io.rew) io.rew[e] = r;
-      if (io.done) io.done[e] = d ? 1 : 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (packed_layout) {
-        stage[SS_OBS_DIM] = r;
-        stage[SS_OBS_DIM + 1] = d ? 1.f : 0.f;
-      }
-      istage[0] = SS_F2U(inf.ep_ret); istage[1] = SS_F2U(inf.ep_len);
-      istage[2] = (uint32_t)inf.bad_transition; istage[3] = (uint32_t)inf.steps_reached; istage[4] = (uint32_t)inf.update_terrain;
-#else
-      if (io.info) io.info[e] = inf;
-      if (io.packed) {
-        float* pk = io.packed + (size_t)e * (SS_OBS_DIM + 2);
-        for (int i = 0; i < SS_OBS_DIM; ++i) pk[i] = op_direct[i];
-        pk[SS_OBS_DIM] = r;
-        pk[SS_OBS_DIM + 1] = d ? 1.f : 0.f;
-      }
-#endif
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Fo[(F_POS + i) * np] = pos[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Fo[(F_QUAT + i) * np] = quat[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { Fo[(F_VEL + i) * np] = v0.w[i]; Fo[(F_VEL + 3 + i) * np] = v0.v[i]; }
-      if (advanced || do_reset) store_cache(P, e, c);
-      Fo[F_POT * np] = pot_prev;
-      Fo[F_ZINIT * np] = z_init;
-      Fo[F_EPRET * np] = ep_ret;
-      Fo[F_NNDR * np] = nn_dr;
-      P.istate[e + I_N * np] = n;
-      P.istate[e + I_COUNT * np] = count;
-      P.istate[e + I_ELAPSED * np] = elapsed;
-      P.istate[e + I_RNG * np] = (int)ctr;
-      P.istate[e + I_FLAGS * np] = flags;
-    }
-  }
-#if defined(__HIP_DEVICE_COMPILE__)
-  {
-    SS_MEMBAR();
-    const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
-    const int nvalid = min(kEnvsPerWave, P.n - env0);
-    // copy the staged block (nfl floats from the start of the LDS staging area) to dst: float4 when dst is 16-byte aligned
-    auto copy_block = [&](float* dst, int nfl) {
-      if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
-        const int n4 = nfl >> 2;
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        const float4* s4 = reinterpret_cast<const float4*>(lds);
-#pragma unroll 1
-        for (int g = lane; g < n4; g += kWave) d4[g] = s4[g];
-        for (int g = (n4 << 2) + lane; g < nfl; g += kWave) dst[g] = lds[g];
-      } else {
-#pragma unroll 1
-        for (int g = lane; g < nfl; g += kWave) dst[g] = lds[g];
-      }
-    };
-    if (io.obs) {
-      float* og = io.obs + (size_t)env0 * SS_OBS_DIM;
-      if (!packed_layout) {
-        copy_block(og, nvalid * SS_OBS_DIM);
-      } else {                                   // both outputs requested: the staging has the packed layout
-#pragma unroll 1
-        for (int g = lane; g < nvalid * SS_OBS_DIM; g += kWave) {
-          const int el = g / SS_OBS_DIM, idx = g - el * SS_OBS_DIM;
-          og[g] = lds[el * kPackW + idx];
-        }
-      }
-    }
-    if (io.packed) {
-      float* pk = io.packed + (size_t)env0 * kPackW;
-      if constexpr (ROLLOUT) pk += (long long)kstep * io.packed_step_stride;
-      copy_block(pk, nvalid * kPackW);
-    }
-    if (io.info) {
-      uint32_t* ig = reinterpret_cast<uint32_t*>(io.info + env0);
-      const uint32_t* is = reinterpret_cast<const uint32_t*>(lds) + kInfoBase;
-      for (int g = lane; g < nvalid * 5; g += kWave) ig[g] = is[g];
-    }
-    if constexpr (!ROLLOUT) {
-      if (io.peers) {
-        constexpr int kPack = SS_OBS_DIM + 2;
-        const PeerTable* T = io.peers;
-        const int G = T->count;
-        const size_t row0 = (size_t)T->rank * (size_t)T->n_local + (size_t)env0;
-#pragma unroll 1
-        for (int p = 0; p < G; ++p) copy_block(T->dst[p] + row0 * kPack, nvalid * kPack);
-        __threadfence_system();                                   // my rows are visible to every agent ...
-        if (lane == 0) {
-          const uint32_t prev = atomicAdd(T->done_counter, 1u);   // ... before I count myself
-          if ((prev + 1u) % gridDim.x == 0u) {                    // last workgroup of this launch (launches are stream-ordered)
-            __threadfence_system();
-            for (int p = 0; p < G; ++p)
-              __hip_atomic_store(T->flag[p] + T->rank, io.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        }
-      }
-    }
-  }
-#endif
-#undef SS_OBS
-  if constexpr (ROLLOUT) {
-    // the next step starts from the LDS copy of the state: refresh what the env logic changed (this lane's world)
+  // 11. output stage (emit_outputs): inline, or on helper 1 in the three-helper rollout kernel
+  if constexpr (ROLLOUT || kOffload) {
+    // the LDS copy of the state is what comes next (the next step, helper 1's output stage): refresh what the env logic changed
     if (do_reset) {
       L.s(S_POS + 0) = pos[0]; L.s(S_POS + 1) = m * pos[1]; L.s(S_POS + 2) = pos[2];
       L.s(S_QUAT + 0) = quat[0]; L.s(S_QUAT + 1) = m * quat[1]; L.s(S_QUAT + 2) = quat[2]; L.s(S_QUAT + 3) = m * quat[3];
@@ -778,14 +835,59 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
         L.s(S_STN + sl * 3 + 0) = c.nrm[sl][0]; L.s(S_STN + sl * 3 + 1) = m * c.nrm[sl][1]; L.s(S_STN + sl * 3 + 2) = c.nrm[sl][2];
       }
     }
-    SS_MEMBAR();
   }
+  if constexpr (kOffload) {
+    L.hs(kHandOut + 0) = r;
+    L.hs(kHandOut + 1) = z_init;
+    L.hs(kHandOut + 2) = inf.ep_ret;
+    const int bits = (d ? 1 : 0) | (inf.bad_transition << 1) | (inf.update_terrain << 2) | ((do_reset ? 1 : 0) << 3) | (flags << 4) |
+                     (inf.steps_reached << 8) | ((int)inf.ep_len << 16);
+    L.hs(kHandOut2 + 0) = __builtin_bit_cast(float, bits);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { L.hs(kHandOut + 3 + i) = c.p[1][i]; L.hs(kHandOut + 8 + i) = c.p[2][i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { L.hs(kHandOut + 6 + i) = c.tilt[1][i]; L.hs(kHandOut + 11 + i) = c.tilt[2][i]; }
+  } else {
+    StepOut o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.pos[i] = pos[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.quat[i] = quat[i];
+    o.v0 = v0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) { o.qt[k] = qt[k]; o.qdt[k] = qdt[k]; }
+    o.r = r; o.z_init = z_init; o.roll = roll; o.pitch = pitch; o.cyaw = cyaw; o.syaw = syaw;
+    o.d = d ? 1 : 0; o.flags = flags; o.do_reset = do_reset ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o.tgt[0][i] = c.p[1][i]; o.tgt[1][i] = c.p[2][i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { o.tgt[0][3 + i] = c.tilt[1][i]; o.tgt[1][3 + i] = c.tilt[2][i]; }
+    o.inf = inf;
+    emit_outputs<Model, ROLLOUT>(P, io, o, e, side, valid, lane, lane_global, kstep, lds);
+  }
+  if (valid && side == 0) {            // the env-level scalars
+    float* Fo = P.fstate + e;
+    if (advanced || do_reset) store_cache(P, e, c);
+    Fo[F_POT * np] = pot_prev;
+    Fo[F_ZINIT * np] = z_init;
+    Fo[F_EPRET * np] = ep_ret;
+    Fo[F_NNDR * np] = nn_dr;
+    P.istate[e + I_N * np] = n;
+    P.istate[e + I_COUNT * np] = count;
+    P.istate[e + I_ELAPSED * np] = elapsed;
+    P.istate[e + I_RNG * np] = (int)ctr;
+    P.istate[e + I_FLAGS * np] = flags;
+  }
+  SS_MEMBAR();
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
   SS_PROF(13);
   if (lane == 0 && P.prof)
     for (int i = 0; i < 16; ++i) atomicAdd(P.prof + i, (unsigned long long)prof.t[i]);
 #endif
   }   // control steps of this launch
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (out_offload(HELPERS, ROLLOUT)) __syncthreads();   // helper 1 emits the last step's outputs
+#endif
 }
 
 #ifndef SS_HOST_HARNESS
@@ -807,7 +909,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
   } else {
     const Lds L{lds, lane};
 #pragma unroll 1
-    for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L, [] {});
+    for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L, [](int) {});
   }
 }
 // K control steps per launch (ss_rollout_random): same code, state resident in LDS between the steps
@@ -832,11 +934,18 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
     for (int kstep = 0; kstep < io.nsteps; ++kstep)
 #pragma unroll 1
       for (int k = 0; k < SS_NUM_SUBSTEPS; ++k)
-        helper_substep<Model, HELPERS>(wave - 1, L, [&] {
+        helper_substep<Model, HELPERS>(wave - 1, L, [&](int helper) {
+          if (k != 0) return;
           // the next control step's actions, while the main wavefront is in pass 1 / 2 of this step's first substep
-          if (HELPERS > 1 && k == 0 && kstep + 1 < io.nsteps)
+          if (HELPERS > 1 && helper == HELPERS - 1 && kstep + 1 < io.nsteps)
             random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
+          // the previous control step's outputs
+          if (out_offload(HELPERS, true) && helper == 1 && kstep > 0) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, kstep - 1, lds);
         });
+    if constexpr (out_offload(HELPERS, true)) {
+      __syncthreads();                 // the last step's results are in the hand-off region
+      if (wave == 2) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, io.nsteps - 1, lds);
+    }
   }
 }
 #endif  // SS_HOST_HARNESS

@@ -57,4 +57,14 @@ def ensure_ranks(n, script_argv=None, module=None):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("GPU_MAX_HW_QUEUES", "8")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(launcher_command(n, argv, module=module), env=env)
+    # free_port() releases the port before the launcher binds it: if somebody else takes it in between, the rendezvous fails
+    # within seconds -- one more attempt with a fresh port then (a run that fails later is not repeated)
+    import time
+    for attempt in (0, 1):
+        t0 = time.time()
+        rc = subprocess.call(launcher_command(n, argv, module=module), env=env)
+        if rc == 0 or attempt == 1 or time.time() - t0 > 15.0:
+            return rc
+        print("steppingstone_amd.launch: the ranks exited with %d after %.1f s; retrying once with another port" % (rc, time.time() - t0),
+              file=sys.stderr, flush=True)
+    return rc
