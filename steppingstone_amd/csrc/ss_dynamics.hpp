@@ -43,7 +43,7 @@ constexpr int kWave = 64;
 constexpr int kEnvsPerWave = 32;
 constexpr int kLdsSlots = 40;          // 40 float4 = 640 B per lane = 40,960 B per wavefront: four wavefronts (one per SIMD) per CU
 constexpr int kSlotsA = 20;            // region A: ABA-phase body twists (78 scalars), then the contact operators G and T
-constexpr int kLdsG = 0;               // 6 columns x 3 float2: pelvis twist per unit impulse on the own foot
+constexpr int kLdsC = 0;               // 6 columns x 3 float2: own-foot twist per unit impulse on the PARTNER's foot (T . mirror(G_partner))
 constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist per unit pelvis twist
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 // helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
@@ -325,25 +325,39 @@ struct LamPair { ssf2 a[3], b[3]; };
 // Part B needs the spine records and the base factor as well: up the spine, base solve, down to the pelvis (G) and the foot
 // (Lambda_own).  The helper wavefronts run A while the main wavefront is still in the spine and the base solve.
 struct OpCarry { SV2 p; ssf2 ul2[NH]; };
-template <class Model, int CPAIR>
-SSD void operator_pair_a(const JointCache& jc_in, const Lds& L, JointCache& jc, OpCarry& oc) {
+// opaque register copies of the records a part reads (see above)
+SSD void operator_records_leg(const JointCache& jc_in, JointCache& jc) {
 #pragma unroll
   for (int k = 3; k < 8; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
-  {
-    SV2 d;
+}
+SSD void operator_records_spine(const JointCache& jc_in, JointCache& jc) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      d.w[m] = ssf2{2 * CPAIR == m ? 1.f : 0.f, 2 * CPAIR + 1 == m ? 1.f : 0.f};
-      d.v[m] = ssf2{2 * CPAIR == m + 3 ? 1.f : 0.f, 2 * CPAIR + 1 == m + 3 ? 1.f : 0.f};
-    }
-    static_for<3, 8>([&](auto Jc) { d = imp_down_pair<Model, decltype(Jc)::value>(jc, d); });
-    L.q2(kLdsT + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
-    L.q2(kLdsT + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
-    L.q2(kLdsT + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
-    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
-    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
-    L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+  for (int k = 0; k < 3; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { jc.L0.l[i] = jc_in.L0.l[i]; SS_REG(jc.L0.l[i]); }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { jc.L0.di[i] = jc_in.L0.di[i]; SS_REG(jc.L0.di[i]); }
+}
+// part A, first half: T columns 2c, 2c+1 -> LDS (every T column must be there before any part B: C needs all six)
+template <class Model, int CPAIR>
+SSD void operator_T(const JointCache& jc, const Lds& L) {
+  SV2 d;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    d.w[m] = ssf2{2 * CPAIR == m ? 1.f : 0.f, 2 * CPAIR + 1 == m ? 1.f : 0.f};
+    d.v[m] = ssf2{2 * CPAIR == m + 3 ? 1.f : 0.f, 2 * CPAIR + 1 == m + 3 ? 1.f : 0.f};
   }
+  static_for<3, 8>([&](auto Jc) { d = imp_down_pair<Model, decltype(Jc)::value>(jc, d); });
+  L.q2(kLdsT + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
+  L.q2(kLdsT + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
+  L.q2(kLdsT + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
+  L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
+  L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
+  L.q2(kLdsT + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+}
+// part A, second half: unit impulses on the own foot (columns 2c, 2c+1) carried up to the pelvis
+template <class Model, int CPAIR>
+SSD void operator_up(const JointCache& jc, OpCarry& oc) {
   SV2 p;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
@@ -354,35 +368,53 @@ SSD void operator_pair_a(const JointCache& jc_in, const Lds& L, JointCache& jc, 
   oc.p = p;
 }
 template <class Model, int CPAIR>
-SSD LamPair operator_pair_b(const JointCache& jc_in, const Lds& L, JointCache& jc, OpCarry& oc) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) jc.r[k] = opaque_rec(jc_in.r[k]);
-#pragma unroll
-  for (int i = 0; i < 15; ++i) { jc.L0.l[i] = jc_in.L0.l[i]; SS_REG(jc.L0.l[i]); }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { jc.L0.di[i] = jc_in.L0.di[i]; SS_REG(jc.L0.di[i]); }
+SSD void operator_pair_a(const JointCache& jc_in, const Lds& L, JointCache& jc, OpCarry& oc) {
+  operator_records_leg(jc_in, jc);
+  operator_T<Model, CPAIR>(jc, L);
+  operator_up<Model, CPAIR>(jc, oc);
+}
+// part B: up the spine, base solve, down to the pelvis: G columns (pelvis twist per unit impulse on the own foot).  What the
+// PGS needs of G is its effect on the OTHER foot, so the lane pair swaps the columns (mirrored on receipt) and each lane
+// stores C = T_own . mirror(G_partner): own-foot twist per unit impulse on the partner's foot -- one 6x6 operator per sweep
+// in the PGS instead of two (18 instead of 36 packed FMAs and LDS reads per sweep).  Then down the own leg: Lambda_own.
+template <class Model, int CPAIR>
+SSD LamPair operator_pair_b(const Lds& L, const JointCache& jc, OpCarry& oc) {
   SV2 p = oc.p;
   static_rfor<2, 0>([&](auto Jc) { p = imp_up_pair<Model, decltype(Jc)::value>(jc, oc.ul2, p); });
   SV2 d = chol6_solve_neg_pair(jc.L0, p);
   static_for<0, 3>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, oc.ul2, d); });
-  L.q2(kLdsG + (2 * CPAIR) * 3 + 0) = make_float2(d.w[0].x, d.w[1].x);
-  L.q2(kLdsG + (2 * CPAIR) * 3 + 1) = make_float2(d.w[2].x, d.v[0].x);
-  L.q2(kLdsG + (2 * CPAIR) * 3 + 2) = make_float2(d.v[1].x, d.v[2].x);
-  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 0) = make_float2(d.w[0].y, d.w[1].y);
-  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 1) = make_float2(d.w[2].y, d.v[0].y);
-  L.q2(kLdsG + (2 * CPAIR + 1) * 3 + 2) = make_float2(d.v[1].y, d.v[2].y);
+  {
+    // partner's columns 2c, 2c+1 in this lane's world (y-mirror: axial part (-,+,-), polar part (+,-,+))
+    ssf2 go[6];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const float sw = (m == 1) ? 1.f : -1.f, sv = (m == 1) ? -1.f : 1.f;
+      go[m] = ssf2{sw * xchg(d.w[m].x), sw * xchg(d.w[m].y)};
+      go[3 + m] = ssf2{sv * xchg(d.v[m].x), sv * xchg(d.v[m].y)};
+    }
+    ssf2 ca[3], cb[3];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+      const ssf2 ga = {go[l].x, go[l].x}, gb = {go[l].y, go[l].y};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float2 t = L.q2(kLdsT + l * 3 + i);
+        const ssf2 t2 = {t.x, t.y};
+        if (l == 0) { ca[i] = t2 * ga; cb[i] = t2 * gb; }
+        else { ca[i] = t2 * ga + ca[i]; cb[i] = t2 * gb + cb[i]; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      L.q2(kLdsC + (2 * CPAIR) * 3 + i) = make_float2(ca[i].x, ca[i].y);
+      L.q2(kLdsC + (2 * CPAIR + 1) * 3 + i) = make_float2(cb[i].x, cb[i].y);
+    }
+  }
   static_for<3, 8>([&](auto Jc) { d = imp_down_pair_loaded<Model, decltype(Jc)::value>(jc, oc.ul2, d); });
   LamPair o;
   o.a[0] = ssf2{d.w[0].x, d.w[1].x}; o.a[1] = ssf2{d.w[2].x, d.v[0].x}; o.a[2] = ssf2{d.v[1].x, d.v[2].x};
   o.b[0] = ssf2{d.w[0].y, d.w[1].y}; o.b[1] = ssf2{d.w[2].y, d.v[0].y}; o.b[2] = ssf2{d.v[1].y, d.v[2].y};
   return o;
-}
-template <class Model, int CPAIR>
-SSD LamPair operator_pair(const JointCache& jc_in, const Lds& L) {
-  JointCache jc;
-  OpCarry oc;
-  operator_pair_a<Model, CPAIR>(jc_in, L, jc, oc);
-  return operator_pair_b<Model, CPAIR>(jc_in, L, jc, oc);
 }
 
 // Forward kinematics of spine + own leg and contact detection of the own sole's four corners against the three active
@@ -615,10 +647,11 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
   for (int i = 0; i < 15; ++i) jin.L0.l[i] = L.hs(kHandL0 + i);
 #pragma unroll
   for (int i = 0; i < 6; ++i) jin.L0.di[i] = L.hs(kHandL0 + 15 + i);
+  operator_records_spine(jin, jc);
   static_for<0, 3>([&](auto Cc) {
     constexpr int c = decltype(Cc)::value;
     if (HELPERS == 1 || helper == c) {
-      const LamPair lp = operator_pair_b<Model, c>(jin, L, jc, oc[HELPERS == 1 ? c : 0]);
+      const LamPair lp = operator_pair_b<Model, c>(L, jc, oc[HELPERS == 1 ? c : 0]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         L.hs(kHandLc + (2 * c) * 6 + 2 * i) = lp.a[i].x; L.hs(kHandLc + (2 * c) * 6 + 2 * i + 1) = lp.a[i].y;
@@ -1140,28 +1173,17 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #pragma unroll 1
       for (int it = 0; it < kCoupled; ++it) {
         sweep();
-        // pelvis twist change caused by this sweep's own-foot impulses: G dW; the partner's one, mirrored, moves
-        // this foot through T
-        ssf2 dpp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        // the partner's sweep impulses (its own world, as they are) move this foot through C = T_own . mirror(G_partner)
+        ssf2 dWo[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dWo[i] = ssf2{xchg(dWp[i].x), xchg(dWp[i].y)};
 #pragma unroll
         for (int l = 0; l < 6; ++l) {
-          const float sc = (l & 1) ? dWp[l >> 1].y : dWp[l >> 1].x;
+          const float sc = (l & 1) ? dWo[l >> 1].y : dWo[l >> 1].x;
           const ssf2 s2 = {sc, sc};
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            const float2 c = L.q2(kLdsG + l * 3 + i);
-            dpp[i] = ssf2{c.x, c.y} * s2 + dpp[i];
-          }
-        }
-        SV dp = {{dpp[0].x, dpp[0].y, dpp[1].x}, {dpp[1].y, dpp[2].x, dpp[2].y}};
-        const SV dpo = xchg_sv(dp);
-        const float dpv[6] = {dpo.w[0], dpo.w[1], dpo.w[2], dpo.v[0], dpo.v[1], dpo.v[2]};
-#pragma unroll
-        for (int l = 0; l < 6; ++l) {
-          const ssf2 s2 = {dpv[l], dpv[l]};
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const float2 c = L.q2(kLdsT + l * 3 + i);
+            const float2 c = L.q2(kLdsC + l * 3 + i);
             Vp[i] = ssf2{c.x, c.y} * s2 + Vp[i];
           }
         }
@@ -1196,9 +1218,15 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   };
   if constexpr (HELPERS == 0) {     // one block, the operators first (before the rows occupy the registers)
     if (in_contact) {
+      JointCache jo;                   // opaque copies of the spine + leg records and the base factor
+      operator_records_leg(jc, jo);
+      operator_records_spine(jc, jo);
+      static_for<0, 3>([&](auto Cc) { operator_T<Model, decltype(Cc)::value>(jo, L); });    // all six T columns first: C needs them
       static_for<0, 3>([&](auto Cc) {
         constexpr int c = decltype(Cc)::value;
-        const LamPair lp = operator_pair<Model, c>(jc, L);
+        OpCarry oc;
+        operator_up<Model, c>(jo, oc);
+        const LamPair lp = operator_pair_b<Model, c>(L, jo, oc);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { Lc[2 * c][i] = lp.a[i]; Lc[2 * c + 1][i] = lp.b[i]; }
       });
