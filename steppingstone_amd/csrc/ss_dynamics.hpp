@@ -1170,6 +1170,11 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #else
       constexpr int kCoupled = kPgsIters - 1;   // after the last sweep nothing reads the foot twist any more: its coupling is dead
 #endif
+      ssf2 Cc[6][3];                   // read once (the compiler parks what does not fit in AGPRs: 0.0514 -> 0.0511 ms/step)
+#pragma unroll
+      for (int l = 0; l < 6; ++l)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float2 c = L.q2(kLdsC + l * 3 + i); Cc[l][i] = ssf2{c.x, c.y}; }
 #pragma unroll 1
       for (int it = 0; it < kCoupled; ++it) {
         sweep();
@@ -1183,8 +1188,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
           const ssf2 s2 = {sc, sc};
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            const float2 c = L.q2(kLdsC + l * 3 + i);
-            Vp[i] = ssf2{c.x, c.y} * s2 + Vp[i];
+            Vp[i] = Cc[l][i] * s2 + Vp[i];
           }
         }
       }
