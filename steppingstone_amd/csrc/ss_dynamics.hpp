@@ -1175,6 +1175,10 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int l = 0; l < 6; ++l)
 #pragma unroll
         for (int i = 0; i < 3; ++i) { const float2 c = L.q2(kLdsC + l * 3 + i); Cc[l][i] = ssf2{c.x, c.y}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // all LDS reads land before the loop: otherwise its body carries eleven `s_waitcnt lgkmcnt(n)` for the first iteration's sake
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), leave vmcnt / expcnt alone
+#endif
 #pragma unroll 1
       for (int it = 0; it < kCoupled; ++it) {
         sweep();
