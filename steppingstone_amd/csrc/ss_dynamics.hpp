@@ -1179,7 +1179,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       // all LDS reads land before the loop: otherwise its body carries eleven `s_waitcnt lgkmcnt(n)` for the first iteration's sake
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), leave vmcnt / expcnt alone
 #endif
-#pragma unroll 1
+#pragma unroll 1                       // (unrolled by 2 or fully: 0.0522 vs 0.0504 ms/step -- code size, register moves stay)
       for (int it = 0; it < kCoupled; ++it) {
         sweep();
         // the partner's sweep impulses (its own world, as they are) move this foot through C = T_own . mirror(G_partner)
