@@ -8,14 +8,16 @@
 // pair (one DPP/shuffle exchange each, mirrored on receipt) is
 //     pass 2: the leg's articulated inertia + bias at the pelvis, the arm's at the torso      (2 x 27 floats)
 //     detect: "any contact" flag
-//     PGS:    per sweep the pelvis twist change caused by the other foot's impulses            (6 floats)
+//     operators: the pelvis-twist columns G of the own foot's unit impulses, once per substep  (36 floats)
+//     PGS:    per sweep the other foot's wrench increments                                     (6 floats)
 //     final:  the pelvis bias impulse of the other leg                                         (6 floats)
 // The 4096-env workload therefore runs on 128 wavefronts of 32 envs and every serial chain (ABA sweeps, Lambda^-1
 // columns, contact rows, PGS) is half as long as with one env per lane.
 //
 // Per lane: up to 512 VGPR+AGPR and a private 640-byte share of LDS (40 KiB per wavefront, one wavefront per
 // workgroup, four workgroups = one per SIMD on a CU; no barriers: lanes only read their own columns).  Region A
-// (20 float4-slots): the contact operators G and T, 6 columns x 3 float2 items each, 8-byte lane stride (ds_*_b64).
+// (20 float4-slots): the contact operators C (own-foot twist per unit impulse on the partner's foot) and T, 6 columns x 3
+// float2 items each, 8-byte lane stride (ds_*_b64); afterwards the staging area of the step's output rows.
 // Region B (scalars, element-major, ds_*_b32): actions, q, qd, free qd, base pose + twist, stones.  The link twists,
 // the 12 joint records, the 12 PGS rows and Lambda_own live in registers (the compiler parks them in AGPRs).
 #pragma once
@@ -42,7 +44,7 @@ constexpr float kVcorrMax = 2.0f;
 constexpr int kWave = 64;
 constexpr int kEnvsPerWave = 32;
 constexpr int kLdsSlots = 40;          // 40 float4 = 640 B per lane = 40,960 B per wavefront: four wavefronts (one per SIMD) per CU
-constexpr int kSlotsA = 20;            // region A: ABA-phase body twists (78 scalars), then the contact operators G and T
+constexpr int kSlotsA = 20;            // region A: the contact operators C and T (72 floats per lane), output staging
 constexpr int kLdsC = 0;               // 6 columns x 3 float2: own-foot twist per unit impulse on the PARTNER's foot (T . mirror(G_partner))
 constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist per unit pelvis twist
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
@@ -107,7 +109,6 @@ struct Lds {       // lane-private view of the workgroup's LDS
   SSD float2& q2(int item) const { return reinterpret_cast<float2*>(base)[item * kWave + lane]; }   // region A, 8-B items
   SSD float& s(int idx) const { return base[kScalarBase + idx * kWave + lane]; }   // region B scalar
   SSD float& hs(int idx) const { return base[kHandBase + idx * kWave + lane]; }    // hand-off scalar (helper variant)
-  SSD float& av(int idx) const { return base[idx * kWave + lane]; }                // ABA-phase scalar over region A
 };
 
 struct Stones {    // the three active stones n-1, n, n+1: centre, unit normal, tilts (x, y)
@@ -659,7 +660,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
       }
     }
   });
-  __syncthreads();                                   // #3: G, T and Lambda_own are ready
+  __syncthreads();                                   // #3: C, T and Lambda_own are ready
 }
 #endif
 
@@ -1179,7 +1180,8 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       // all LDS reads land before the loop: otherwise its body carries eleven `s_waitcnt lgkmcnt(n)` for the first iteration's sake
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), leave vmcnt / expcnt alone
 #endif
-#pragma unroll 1                       // (unrolled by 2 or fully: 0.0522 vs 0.0504 ms/step -- code size, register moves stay)
+#pragma unroll 1                       // (unrolled by 2 or fully: 0.0522 vs 0.0504 ms/step; C formed by the helpers after barrier #3
+                                       // behind a sixth barrier instead of inside part B: no gain either)
       for (int it = 0; it < kCoupled; ++it) {
         sweep();
         // the partner's sweep impulses (its own world, as they are) move this foot through C = T_own . mirror(G_partner)
@@ -1244,7 +1246,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   } else {
     if (in_contact) rows_free();
 #if defined(__HIP_DEVICE_COMPILE__)
-    __syncthreads();                 // #3: the helper wavefront(s) have written G, T and Lambda_own
+    __syncthreads();                 // #3: the helper wavefront(s) have written C, T and Lambda_own
 #endif
     if (in_contact) solve();
   }
