@@ -53,6 +53,12 @@ constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 constexpr int kHandJc = 0, kHandL0 = 72, kHandLc = 93, kHandDet = 129, kHandAct = 146, kHandFloats = 158, kHandCs = kHandLc;   // Det: Rf 9, pen 4 (single-helper variant only), flags (active | cslot << 4 | contact << 12 | on_target << 13), sole 3; Act: the next step's 12 actions (rollout kernel); Cs: cos[12], sin[12] of the joint angles, aliasing Lc (dead between barriers #0 and #2)
 // The directions of the 12 contact rows (36 floats) and the 4 Baumgarte terms, computed by helper 0: they take the place of the
 // leg joint records once every helper has loaded those (written after barrier #2, read by the main wavefront after #3).
+// The velocity-product bias forces of the massive spine bodies (3, 2, 1) and of the base, computed by helper 1 between barriers
+// #0b and #1 (three-helper variant): 4 x 6 floats in the place of the spine joint records, which the main wavefront writes only
+// at the end of the #1 -> #2 window (after it has read the biases).
+constexpr bool bias_offload(int helpers) { return helpers >= 3; }
+constexpr int kHandBias = kHandJc;
+static_assert(24 <= 3 * 9, "biases fit the spine records' place");
 constexpr int kHandRows = kHandJc + 3 * 9;
 // ... with three helpers; a single helper is the critical path in its windows already (16384 envs: 0.0676 vs 0.0609 ms/step)
 constexpr bool rows_offload(int helpers) { return helpers >= 3; }
@@ -613,6 +619,30 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
       for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
     }
   }
+  if constexpr (bias_offload(HELPERS)) {
+    if (helper == 1) {                 // spine velocities from the base twist, then the bias forces of bodies 1..3 and 0
+      const SV v0 = base_twist(L);
+      float qd3[3], cs3[3], sn3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { qd3[k] = L.s(S_QD + k); cs3[k] = L.hs(kHandCs + k); sn3[k] = L.hs(kHandCs + NH + k); }
+      SS_MEMBAR();
+      SV prev = v0;
+      static_for<0, 3>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value, bd = j + 1;
+        SV v = xmotion<Model, j>(cs3[j], sn3[j], prev);
+        v.w[kAxis[j]] += qd3[j];
+        prev = v;
+        if constexpr (Model::mass[bd] != 0.f) {
+          const SV pb = body_bias<Model, bd>(v);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) { L.hs(kHandBias + bd * 6 + m) = pb.w[m]; L.hs(kHandBias + bd * 6 + 3 + m) = pb.v[m]; }
+        }
+      });
+      const SV pb0 = body_bias<Model, 0>(v0);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { L.hs(kHandBias + m) = pb0.w[m]; L.hs(kHandBias + 3 + m) = pb0.v[m]; }
+    }
+  }
   extra(helper);
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
   JointCache jin, jc;
@@ -922,7 +952,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         constexpr int j = decltype(Jc)::value, bd = j + 1;
         if constexpr (Model::mass[bd] != 0.f) {
           abi_add_body<Model, bd>(Is);
-          SV pb = body_bias<Model, bd>(vs[j]);
+          SV pb;
+          if constexpr (bias_offload(HELPERS)) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { pb.w[m] = L.hs(kHandBias + bd * 6 + m); pb.v[m] = L.hs(kHandBias + bd * 6 + 3 + m); }
+          } else {
+            pb = body_bias<Model, bd>(vs[j]);
+          }
 #pragma unroll
           for (int m = 0; m < 3; ++m) { ps.w[m] += pb.w[m]; ps.v[m] += pb.v[m]; }
         }
@@ -942,7 +978,13 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     {
       ABI I0 = acc0;
       abi_add_body<Model, 0>(I0);
-      SV pb = body_bias<Model, 0>(v0);
+      SV pb;
+      if constexpr (bias_offload(HELPERS)) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { pb.w[m] = L.hs(kHandBias + m); pb.v[m] = L.hs(kHandBias + 3 + m); }
+      } else {
+        pb = body_bias<Model, 0>(v0);
+      }
       SV p0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { p0.w[i] = pacc0.w[i] + pb.w[i]; p0.v[i] = pacc0.v[i] + pb.v[i]; }
