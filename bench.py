@@ -233,8 +233,10 @@ def main():
         raise SystemExit(rc)
     rank, local_rank, world = launch.rank_info()
     if args.dry_launch:
-        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
-                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        # one write per line: the ranks share the launcher's stdout, and print() sends the text and the newline separately
+        sys.stdout.write(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
+                                     "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}) + "\n")
+        sys.stdout.flush()
         return
 
     import torch
@@ -242,13 +244,21 @@ def main():
     from steppingstone_amd.distributed import ShardedVecEnv
     from steppingstone_amd.envs import SteppingStoneVecEnv
 
+    # Test hook (tests/test_gpu_two_ranks.py): SS_BENCH_TEST_TRANSPORT=gloo runs every rank on cuda:0 with gloo as the transport, so
+    # that the N > 1 code path executes end to end on a one-GPU box.  The line it prints says so and is never a measurement.
+    test_transport = os.environ.get("SS_BENCH_TEST_TRANSPORT", "")
+    if test_transport:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force = os.environ.get("SS_FORCE_COLLECTIVE") == "1"      # world 1 under torchrun: still go through RCCL
     use_dist = world > 1 or (force and launch.launched())
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if test_transport:
+            dist.init_process_group(test_transport)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_local = args.envs_per_gpu
     local = SteppingStoneVecEnv(args.env, n_local, seed=0, device=dev, env_id_offset=rank * n_local, return_numpy=False)
@@ -376,10 +386,12 @@ def main():
                                    % (args.env, n_local, args.curriculum, " (flat terrain)" if not args.curriculum else ""),
                        "envs_total": total_envs,
                        "parallelism": "env-shard x%d%s" % (world, "+allgather" if gather else ""),
-                       "ranks": world, "collective": (("RCCL all_gather_into_tensor of [32,%d,62] f32 per 32-step chunk, %d ranks"
-                                                       if chunked else "RCCL all_gather_into_tensor of [%d,62] f32 per step, %d ranks")
-                                                      % (n_local, world)) if gather else None,
-                       "steps_per_launch": steps_in_launch},
+                       "ranks": world, "collective": ((("%s all_gather_into_tensor of [32,%%d,62] f32 per 32-step chunk, %%d ranks"
+                                                        if chunked else "%s all_gather_into_tensor of [%%d,62] f32 per step, %%d ranks")
+                                                       % (test_transport or "RCCL")) % (n_local, world)) if gather else None,
+                       "steps_per_launch": steps_in_launch,
+                       **({"test_transport": "%s, all ranks on ONE GPU: a functional run of the N > 1 path, not a measurement" % test_transport}
+                          if test_transport else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
@@ -405,7 +417,8 @@ def main():
             out["extra"] = extra_rows(torch, SteppingStoneVecEnv, dev, flop)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        sys.stdout.write(json.dumps(out) + "\n")          # one write: nothing can land inside the line
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

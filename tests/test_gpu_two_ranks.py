@@ -103,3 +103,24 @@ def test_fused_data_parallel_training_keeps_the_replicas_identical():
     torch.manual_seed(8)
     fresh = torch.cat([p.detach().reshape(-1) for p in ppo.ActorCritic(num_ensembles=1).parameters()]).numpy()
     assert fresh.shape == w0.shape and np.abs(w0 - fresh).max() > 1e-5
+
+
+def test_bench_two_rank_path_runs_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver starts it (self-launch, chunked exchange, max over ranks, one JSON line
+    from rank 0) -- with gloo as the transport and both ranks on cuda:0, because this box has one GPU.  Checks the line's
+    shape, not its numbers."""
+    import json
+    import subprocess
+    env = dict(os.environ, SS_BENCH_TEST_TRANSPORT="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "32",
+                          "--envs-per-gpu", "1024"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 1                                             # rank 0 only
+    d = rows[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["warmup"] == 32 and d["scaling"] == "weak"
+    assert d["config"]["envs_total"] == 2048 and d["config"]["ranks"] == 2 and d["config"]["parallelism"] == "env-shard x2+allgather"
+    assert "test_transport" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "no_gather" in d and "per_step_gather" in d and d["roofline"]["frac"] > 0

@@ -9,6 +9,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _rows(text):
+    """JSON objects of the ranks' shared stdout (robust against two ranks' lines landing on one line)"""
+    dec, rows = json.JSONDecoder(), []
+    for line in text.splitlines():
+        line = line.strip()
+        while line.startswith("{"):
+            obj, end = dec.raw_decode(line)
+            rows.append(obj)
+            line = line[end:].strip()
+    return rows
+
+
 def _env():
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -20,7 +32,7 @@ def test_bench_self_launches_two_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], cwd=ROOT, env=_env(),
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    rows = _rows(out.stdout)
     assert sorted(r["rank"] for r in rows) == [0, 1] and all(r["world_size"] == 2 for r in rows)
     assert all(r["master"].startswith("127.0.0.1:") for r in rows)
 
@@ -30,7 +42,7 @@ def test_bench_under_an_external_launcher_does_not_relaunch():
     cmd = launch.launcher_command(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"])
     out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
-    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    rows = _rows(out.stdout)
     assert len(rows) == 2                                   # two ranks, each printed once: no nested launch
 
 
