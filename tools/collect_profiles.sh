@@ -11,6 +11,14 @@ cd /tmp && export TMPDIR=/tmp
 ( cd $R && python bench.py ) > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline > $O/${tag}_bench_under_rocprof.json 2>/dev/null
 cp $(ls /tmp/kt/*/*kernel_stats.csv | head -1) $O/${tag}_rocprofv3_kernel_stats.csv
+# per-dispatch durations of the multi-step kernel (the --stats average mixes the 200-step warm-up launch with the timed 1000-step ones)
+python - "$(ls /tmp/kt/*/*kernel_trace.csv | head -1)" > $O/${tag}_rocprofv3_rollout_dispatches.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rollout_kernel" in r["Kernel_Name"]]
+print("kernel,start_ns,duration_ns")
+for r in rows:
+    print('"%s",%s,%d' % (r["Kernel_Name"], r["Start_Timestamp"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+PY
 for N in 4096 32768; do
   rm -rf /tmp/hb
   for C in FETCH_SIZE WRITE_SIZE; do
