@@ -205,6 +205,22 @@ def cpu_baseline(budget=24.0):
 
 
 # ------------------------------------------------------------------------------------------------ the bench
+def launch_shape(W, K, spl, ms_per_step):
+    """The launches of the dominant kernel in this run (warm-up and timed) and the per-launch average a `rocprofv3 --stats`
+    summary of the same command shows for it: the warm-up launch is shorter than the timed ones, so that average is not
+    `kernel_ms` (profiles/*_rocprofv3_rollout_dispatches.csv lists the dispatches one by one)."""
+    def sizes(n):
+        out = []
+        while n > 0:
+            out.append(min(spl, n))
+            n -= out[-1]
+        return out
+    warm, timed = sizes(W), sizes(K)
+    every = warm + timed
+    return {"launch_steps": {"warmup": warm, "timed": timed},
+            "rocprofv3_stats_average_ms_expected": ms_per_step * sum(every) / max(len(every), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,6 +413,7 @@ def main():
                          "traffic_source": traffic_src,
                          "traffic_recorded_at_steps_per_launch": (traffic_rec or {}).get("steps_per_launch", 1 if traffic_rec else None),
                          "kernel": kernel, "kernel_ms": launch_ms, "kernel_ms_per_step": kernel_ms_per_step,
+                         **launch_shape(W, K, steps_in_launch, kernel_ms_per_step),
                          "algorithmic_bytes_per_env_step": algo_per_env_step,
                          "algorithmic_bytes_per_launch": algo_per_launch,
                          "algorithmic_bytes_per_env_step_with_lds_resident_state": algo_k_step,
