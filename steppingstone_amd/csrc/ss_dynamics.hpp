@@ -1129,7 +1129,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       if constexpr (!rows_offload(HELPERS)) jacobian_rows<Model>(det, L, rWp, rB);
   };
   auto solve = [&]() {              // y = Lambda w, PGS, response of the whole tree
-      const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
       float ul[NH];
       if constexpr (HELPERS > 0) {
 #pragma unroll

@@ -618,7 +618,6 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   L.s(S_VV + 0) = gin[10]; L.s(S_VV + 1) = m * gin[11]; L.s(S_VV + 2) = gin[12];
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
-    constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
     const float sg = mirror_flips(jr) ? m : 1.f;
     L.s(S_Q + k) = sg * qin[k];
     L.s(S_QD + k) = sg * qdin[k];
