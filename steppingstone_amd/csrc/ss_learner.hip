@@ -38,7 +38,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
     if (_e != hipSuccess) return fail(-2, std::string(#call) + ": " + hipGetErrorString(_e));  \
   } while (0)
 
-constexpr int kObs = 60, kObsPad = 64, kHid = 256, kAct = 21, kOutPad = 32;
+constexpr int kObs = 60, kHid = 256, kAct = 21, kOutPad = 32;
 constexpr int kActorLayers = 6, kCriticLayers = 5, kMaxEns = 4, kMaxSplit = 8;
 constexpr int kLossRows = 32;      // samples per loss-kernel workgroup (and per row of its partial sums)
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SOFTSIGN = 2, ACT_TANH = 3 };
