@@ -311,6 +311,12 @@ def main():
         run = lambda k, t0: env.rollout_random_chunked(k, t0=t0, gather=gather)             # noqa: E731
     else:
         run = lambda k, t0: env.rollout_random(k, t0=t0, gather=gather)                     # noqa: E731
+    # Clock ramp, before and apart from the W warm-up steps: the GPU leaves its idle power state only after some tens of
+    # milliseconds of load, and a short run (the driver has used --steps 20 --warmup 5) would otherwise time the ramp: 72.8 instead
+    # of 82 M env-steps/s.  Collective-free steps on the local shard (the envs simply are 256 steps further along).
+    PREWARM = 256
+    local.rollout_random(PREWARM, t0=1 << 20, steps_per_launch=PREWARM)
+    sync()
     if W:
         run(W, 0)
     elapsed, main_ev_ms = timed(lambda: run(K, W))
@@ -405,7 +411,7 @@ def main():
                        "ranks": world, "collective": ((("%s all_gather_into_tensor of [32,%%d,62] f32 per 32-step chunk, %%d ranks"
                                                         if chunked else "%s all_gather_into_tensor of [%%d,62] f32 per step, %%d ranks")
                                                        % (test_transport or "RCCL")) % (n_local, world)) if gather else None,
-                       "steps_per_launch": steps_in_launch,
+                       "steps_per_launch": steps_in_launch, "prewarm_steps": PREWARM,
                        **({"test_transport": "%s, all ranks on ONE GPU: a functional run of the N > 1 path, not a measurement" % test_transport}
                           if test_transport else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
