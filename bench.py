@@ -294,8 +294,9 @@ def main():
 
     def timed(fn):
         """wall clock (barrier + synchronize on both sides) and HIP-event time on the launch stream of fn()"""
-        sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(); ev1.record()          # torch creates the HIP events lazily at the first record(): not inside the timed region
+        sync()
         t0 = time.perf_counter()
         ev0.record()
         fn()
