@@ -214,20 +214,51 @@ typedef struct {
   real pw[NB][3];
 } work;
 
-/* Decision margins (tests only): while g_margin points at a real[2] the step records, over all substeps,
- *   [0] the smallest distance of a *state-affecting* discrete decision to its threshold -- contact predicate of a
- *       sole corner against a stone (|min(-d, d+0.10, R-rho)| in metres), winner among two touching stones
- *       (|d_a - d_b|), joint-limit switch (|q-hi|, |q-lo| in radians);
- *   [1] the same for the decisions that only enter reward / done (height, fall, posture bands, joint-at-limit count,
- *       target radius).
- * An fp32 implementation with a different operation order may legitimately take the other branch when the margin is
- * within rounding distance; tests/test_gpu_parity.py asserts that EVERY env-step outside the tolerance is such a case. */
-static _Thread_local real* g_margin = 0;
-static void margin_note(int which, real m) {
-  if (!g_margin) return;
+/* Discrete decisions (tests only).  Every threshold test of a control step whose outcome changes the result
+ * discontinuously goes through decide(): class 0 = decisions that change the STATE (contact predicate of a sole
+ * corner against a stone, winner among two touching stones, joint-limit switch), class 1 = decisions that only enter
+ * reward / done (height, fall, posture bands, joint-at-limit count, target radius).  The sites are visited in a
+ * data-independent order, so the running index of a site identifies it within a control step.  While g_dec points at
+ * a `decisions` record the step
+ *   - keeps, per class, the smallest distance of a decision to its threshold (metres / radians): margin[2];
+ *   - lists the indices of the decisions that lie within `tol` of their threshold: near[], nnear;
+ *   - inverts the outcome of the decisions listed in force[]: the "other branch" an fp32 implementation with a
+ *     different operation order may legitimately take when the margin is within rounding distance;
+ *   - records the outcome of every decision (record[]) or takes the outcomes from such a record (replay[]) instead of
+ *     evaluating the conditions: a step with frozen decisions is a smooth function of its inputs, which is what the
+ *     first-order sensitivity probe of tests/parity_rule.py differentiates.
+ * tests/test_gpu_parity.py asserts that EVERY env-step of the HIP path agrees with the oracle either as it ran or with
+ * some subset of its near-threshold decisions inverted -- no env-step passes unbounded. */
+typedef struct {
+  real* margin;
+  int seen;
+  int nforce; const int32_t* force;
+  real tol; int32_t* near; int nnear, cap;
+  uint8_t* record; const uint8_t* replay; int ntrace;   /* outcome of decision idx written to / taken from [idx] */
+} decisions;
+static _Thread_local decisions* g_dec = 0;
+#define FAR_MARGIN ((real)1e30)
+static int decide(int which, int cond, real m) {
+  decisions* D = g_dec;
+  if (!D) return cond;
+  int idx = D->seen++;
   if (m < 0) m = -m;
-  if (m < g_margin[which]) g_margin[which] = m;
+  if (D->margin && m < D->margin[which]) D->margin[which] = m;
+  if (D->near && m < D->tol) { if (D->nnear < D->cap) D->near[D->nnear] = idx; D->nnear++; }
+  if (D->replay && idx < D->ntrace) cond = D->replay[idx];
+  for (int k = 0; k < D->nforce; ++k) if (D->force[k] == idx) { cond = !cond; break; }
+  if (D->record && idx < D->ntrace) D->record[idx] = (uint8_t)(cond != 0);
+  return cond;
 }
+
+/* Contact-stage tap (tests only): while g_tap is set, contact_solve() copies its intermediate quantities out so that
+ * tests/np_contact.py can check every one of them against an independent fp64 numpy evaluation of PHYSICS.md 3.3-3.4. */
+typedef struct {
+  real Li[12][12], V0[12], W[8][3][6], bn[8], lam[8][3], nrm[8][3], pen[8];
+  real qdf[NJ], v0f[6], dqd[NJ], dv0[6];
+  int32_t active[8], stone[8];
+} contact_tap;
+static _Thread_local contact_tap* g_tap = 0;
 
 /* ------------------------------------------------------------------------------------------------ dynamics */
 static void kinematics(const sso_model* M, const env_state* s, work* w) {
@@ -253,9 +284,9 @@ static void aba(const sso_model* M, const env_state* s, const real* tau_m, work*
   real tau[NJ], Dadd[NJ];
   for (int j = 0; j < NJ; ++j) {
     real q = s->q[j], qd = s->qd[j], viol = 0, kl = 0, dl = 0;
-    if (q > M->hi[j]) viol = q - M->hi[j]; else if (q < M->lo[j]) viol = q - M->lo[j];
-    if (viol != 0) { kl = M->klim[j]; dl = M->dlim[j]; }
-    margin_note(0, q - M->hi[j]); margin_note(0, q - M->lo[j]);
+    int over = decide(0, q > M->hi[j], q - M->hi[j]), under = decide(0, q < M->lo[j], q - M->lo[j]);
+    if (over) viol = q - M->hi[j]; else if (under) viol = q - M->lo[j];
+    if (over || under) { kl = M->klim[j]; dl = M->dlim[j]; }
     tau[j] = tau_m[j] - M->damping[j] * qd - M->stiffness[j] * (q + h * qd) - kl * (viol + h * qd) - dl * qd;
     Dadd[j] = M->armature[j] + h * (M->damping[j] + dl) + h * h * (M->stiffness[j] + kl);
   }
@@ -385,14 +416,14 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real d = dv[0] * nrm[0] + dv[1] * nrm[1] + dv[2] * nrm[2];
         real lx = dv[0] - d * nrm[0], ly = dv[1] - d * nrm[1], lz = dv[2] - d * nrm[2];
         real rho2 = lx * lx + ly * ly + lz * lz;
-        if (g_margin) {
-          real g1 = -d, g2 = d + (real)0.10, g3 = STONE_R - r_sqrt(rho2);
-          real gm = g1 < g2 ? g1 : g2;
-          if (g3 < gm) gm = g3;
-          margin_note(0, gm);
-          if (gm > 0 && c->active) margin_note(0, d - best);   /* two touching stones: which one wins */
-        }
-        if (d < 0 && d > (real)-0.10 && rho2 < STONE_R * STONE_R && d < best) {
+        real g1 = -d, g2 = d + (real)0.10, g3 = g_dec ? STONE_R - r_sqrt(rho2) : 0;
+        real gm = g1 < g2 ? g1 : g2;
+        if (g3 < gm) gm = g3;
+        int touch = decide(0, d < 0 && d > (real)-0.10 && rho2 < STONE_R * STONE_R, gm);
+        /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
+         * forced against d >= 0) */
+        int wins = decide(0, !c->active || d < best, (touch && c->active) ? d - best : FAR_MARGIN);
+        if (touch && wins) {
           best = d; c->active = 1; c->stone = idx[sl]; c->pen = -d;
           c->n[0] = nrm[0]; c->n[1] = nrm[1]; c->n[2] = nrm[2];
         }
@@ -417,6 +448,14 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
   memset(dv0, 0, sizeof(real) * 6);
   int any = 0;
   for (int k = 0; k < 8; ++k) any |= ct[k].active;
+  if (g_tap) {
+    memset(g_tap, 0, sizeof *g_tap);
+    memcpy(g_tap->qdf, qd_free, sizeof(real) * NJ); memcpy(g_tap->v0f, v0_free, sizeof(real) * 6);
+    for (int k = 0; k < 8; ++k) {
+      g_tap->active[k] = ct[k].active; g_tap->stone[k] = ct[k].active ? ct[k].stone : -1; g_tap->pen[k] = ct[k].pen;
+      memcpy(g_tap->nrm[k], ct[k].n, sizeof(real) * 3);
+    }
+  }
   if (!any) { for (int k = 0; k < 8; ++k) ws->stone[k] = -1; return; }
   const int foot_body[2] = {RFOOT, LFOOT};
   /* Lambda^-1 by 12 unit impulses */
@@ -440,6 +479,7 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     vb[b][SSO_AXIS[j]] += qd_free[j];
   }
   for (int f = 0; f < 2; ++f) for (int k = 0; k < 6; ++k) V[f * 6 + k] = vb[foot_body[f]][k];
+  if (g_tap) memcpy(g_tap->V0, V, sizeof V);
   /* rows */
   real W[8][3][6];
   real bn[8];
@@ -520,6 +560,14 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
   }
   impulse_response(w, fimp, dvb, dqd);
   memcpy(dv0, dvb[0], sizeof(real) * 6);
+  if (g_tap) {
+    memcpy(g_tap->Li, Li, sizeof Li);
+    for (int k = 0; k < 8; ++k) {
+      if (!ct[k].active) continue;
+      memcpy(g_tap->W[k], W[k], sizeof W[k]); g_tap->bn[k] = bn[k]; memcpy(g_tap->lam[k], ct[k].lam, sizeof(real) * 3);
+    }
+    memcpy(g_tap->dqd, dqd, sizeof(real) * NJ); memcpy(g_tap->dv0, dv0, sizeof(real) * 6);
+  }
 }
 
 static void substep(const sso_model* M, env_state* s, const real* tau_m, foot_report* fr, warm_state* ws) {
@@ -714,17 +762,17 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   real progress = pot - s->pot_prev;
   s->pot_prev = advanced ? -planar_dist(s->terrain[s->n], s->pos) / DT_CTRL : pot;
   /* 7-8 */
-  real target_bonus = (s->n == NSTONE - 1 && planar_dist(s->terrain[s->n], s->pos) < (real)0.15) ? 2 : 0;
+  real dist_t = planar_dist(s->terrain[s->n], s->pos);
+  int inside = decide(1, dist_t < (real)0.15, s->n == NSTONE - 1 ? dist_t - (real)0.15 : FAR_MARGIN);
+  real target_bonus = (s->n == NSTONE - 1 && inside) ? 2 : 0;
   real zs = fr.sole[0][2] < fr.sole[1][2] ? fr.sole[0][2] : fr.sole[1][2];
-  real tall_bonus = (s->pos[2] - zs > (real)0.7) ? 2 : -1;
+  real tall_bonus = decide(1, s->pos[2] - zs > (real)0.7, s->pos[2] - zs - (real)0.7) ? 2 : -1;
   int i0 = s->n - 1 < 0 ? 0 : s->n - 1, i2 = s->n + 1 > NSTONE - 1 ? NSTONE - 1 : s->n + 1;
   real zlow = s->terrain[i0][2];
   if (s->terrain[s->n][2] < zlow) zlow = s->terrain[s->n][2];
   if (s->terrain[i2][2] < zlow) zlow = s->terrain[i2][2];
-  int d = tall_bonus < 0 || s->pos[2] < zlow + (real)0.3 || !finite;
-  margin_note(1, s->pos[2] - zs - (real)0.7);
-  margin_note(1, s->pos[2] - zlow - (real)0.3);
-  if (s->n == NSTONE - 1) margin_note(1, planar_dist(s->terrain[s->n], s->pos) - (real)0.15);
+  int fell = decide(1, s->pos[2] < zlow + (real)0.3, s->pos[2] - zlow - (real)0.3);
+  int d = tall_bonus < 0 || fell || !finite;
   int timeout = s->elapsed >= 1000;
   int bad = timeout; /* TimeLimitMask, common/envs_utils.py:59-65: done at the step limit, whatever else ended it */
   d = d || timeout;
@@ -732,18 +780,18 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   real roll, pitch, yaw;
   quat_rpy(s->quat, &roll, &pitch, &yaw);
   real posture = 0;
-  if (!(pitch > (real)-0.2 && pitch < (real)0.4)) posture += r_abs(pitch);
-  if (!(roll > (real)-0.4 && roll < (real)0.4)) posture += r_abs(roll);
-  margin_note(1, pitch + (real)0.2); margin_note(1, pitch - (real)0.4);
-  margin_note(1, roll + (real)0.4); margin_note(1, roll - (real)0.4);
+  real mp = pitch + (real)0.2 < (real)0.4 - pitch ? pitch + (real)0.2 : (real)0.4 - pitch;
+  real mr = roll + (real)0.4 < (real)0.4 - roll ? roll + (real)0.4 : (real)0.4 - roll;
+  if (!decide(1, pitch > (real)-0.2 && pitch < (real)0.4, mp)) posture += r_abs(pitch);
+  if (!decide(1, roll > (real)-0.4 && roll < (real)0.4, mr)) posture += r_abs(roll);
   real e_sum = 0, a2 = 0;
   int at_limit = 0;
   for (int j = 0; j < NJ; ++j) {
     e_sum += r_abs(a[j] * ((real)0.1 * s->qd[j]));
     a2 += a[j] * a[j];
     real mid = (real)0.5 * (M->lo[j] + M->hi[j]);
-    if (r_abs(2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j])) > (real)0.99) at_limit += 1;
-    margin_note(1, (r_abs(2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j])) - (real)0.99) * (real)0.5 * (M->hi[j] - M->lo[j]));
+    real qn = r_abs(2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j]));
+    if (decide(1, qn > (real)0.99, (qn - (real)0.99) * (real)0.5 * (M->hi[j] - M->lo[j]))) at_limit += 1;
   }
   real energy = ((real)4.5 / NJ) * (e_sum / NJ) + ((real)0.225 / NJ) * (a2 / NJ);
   real r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - (real)0.1 * at_limit;
@@ -792,14 +840,71 @@ void sso_step(sso_env* E, const float* act, float* obs, float* rew, uint8_t* don
   for (int e = 0; e < E->num_envs; ++e)
     env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
 }
-/* sso_step that also returns margins[N][2] (see g_margin above) */
+/* sso_step that also returns margins[N][2]: per env the smallest distance of a class-0 / class-1 decision of this
+ * control step to its threshold (see decide() above) */
 void sso_step_margins(sso_env* E, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info, real* margins) {
 #pragma omp parallel for schedule(dynamic, 8)
   for (int e = 0; e < E->num_envs; ++e) {
-    margins[2 * e] = margins[2 * e + 1] = (real)1e30;
-    g_margin = margins + 2 * e;
+    decisions D;
+    memset(&D, 0, sizeof D);
+    margins[2 * e] = margins[2 * e + 1] = FAR_MARGIN;
+    D.margin = margins + 2 * e;
+    g_dec = &D;
     env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
-    g_margin = 0;
+    g_dec = 0;
+  }
+}
+/* sso_step_margins that also lists, per env, the indices of the decisions within `tol` of their threshold:
+ * near[N][cap] (first cap of them) and nnear[N] (their true number, which may exceed cap) */
+void sso_step_near(sso_env* E, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info, real* margins,
+                   double tol, int32_t* near, int32_t* nnear, int cap) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int e = 0; e < E->num_envs; ++e) {
+    decisions D;
+    memset(&D, 0, sizeof D);
+    margins[2 * e] = margins[2 * e + 1] = FAR_MARGIN;
+    D.margin = margins + 2 * e;
+    D.tol = (real)tol; D.near = near + (size_t)e * cap; D.cap = cap;
+    g_dec = &D;
+    env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
+    g_dec = 0;
+    nnear[e] = D.nnear;
+  }
+}
+/* The general form: any of margins [N][2], near [N][cap] + nnear [N], force [N][cap] + nforce [N], record [N][ntrace],
+ * replay [N][ntrace] may be null.  SSO_MAX_DECISIONS bounds the number of decision sites of a control step. */
+#define SSO_MAX_DECISIONS 400
+int sso_max_decisions(void) { return SSO_MAX_DECISIONS; }
+void sso_step_ex(sso_env* E, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info, real* margins, double tol,
+                 int32_t* near, int32_t* nnear, const int32_t* force, const int32_t* nforce, int cap, uint8_t* record,
+                 const uint8_t* replay, int ntrace) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int e = 0; e < E->num_envs; ++e) {
+    decisions D;
+    memset(&D, 0, sizeof D);
+    if (margins) { margins[2 * e] = margins[2 * e + 1] = FAR_MARGIN; D.margin = margins + 2 * e; }
+    if (near) { D.tol = (real)tol; D.near = near + (size_t)e * cap; D.cap = cap; }
+    if (force) { D.force = force + (size_t)e * cap; D.nforce = nforce[e]; }
+    D.ntrace = ntrace;
+    if (record) D.record = record + (size_t)e * ntrace;
+    if (replay) D.replay = replay + (size_t)e * ntrace;
+    g_dec = &D;
+    env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
+    g_dec = 0;
+    if (nnear) nnear[e] = D.nnear;
+  }
+}
+/* sso_step with, per env, the outcome of the decisions force[e][0 .. nforce[e]) inverted */
+void sso_step_forced(sso_env* E, const float* act, float* obs, float* rew, uint8_t* done, sso_info* info,
+                     const int32_t* force, const int32_t* nforce, int cap) {
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int e = 0; e < E->num_envs; ++e) {
+    decisions D;
+    memset(&D, 0, sizeof D);
+    D.force = force + (size_t)e * cap; D.nforce = nforce[e];
+    g_dec = &D;
+    env_step(E, e, act + (size_t)e * NJ, obs + (size_t)e * OBS_DIM, rew + e, done + e, info + e);
+    g_dec = 0;
   }
 }
 void sso_set_curriculum(sso_env* E, int c) {
@@ -901,6 +1006,18 @@ void sso_debug_substeps(sso_env* E, int e, const real* tau_m, int n, int* flags4
   flags4[0] = fr.foot_contact[0]; flags4[1] = fr.foot_contact[1];
   flags4[2] = fr.foot_on_target[0]; flags4[3] = fr.foot_on_target[1];
 }
+/* ONE substep of env e with fixed motor torques (state advanced), with the contact stage's intermediate quantities
+ * copied to *tap (layout: contact_tap above, mirrored by tests/oracle_lib.py) */
+void sso_debug_contact(sso_env* E, int e, const real* tau_m, contact_tap* tap) {
+  foot_report fr;
+  warm_state ws;
+  memset(&fr, 0, sizeof fr);
+  for (int k = 0; k < 8; ++k) ws.stone[k] = -1;
+  g_tap = tap;
+  substep(E->M, &E->e[e], tau_m, &fr, &ws);
+  g_tap = 0;
+}
+int sso_tap_size(void) { return (int)sizeof(contact_tap); }
 /* world position of every body (22 x 3) and rotation (22 x 9) for FK checks */
 void sso_debug_fk(int kind, const real* packed, real* pos, real* rot) {
   sso_env* E = sso_create(kind, 1, 0, 0);

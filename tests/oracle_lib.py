@@ -12,6 +12,16 @@ OBS_DIM, ACT_DIM, STATE_DIM, NCELL = 60, 21, 185, 121
 KIND = {"walker3d": 0, "mike": 1}
 
 
+NEAR_CAP = 6
+MAX_DECISIONS = 400      # sso_max_decisions(): 4 substeps x (42 limit switches + 48 contact predicates) + 26 reward / done tests
+
+
+def tap_dtype(real):
+    return np.dtype([("Li", real, (12, 12)), ("V0", real, (12,)), ("W", real, (8, 3, 6)), ("bn", real, (8,)), ("lam", real, (8, 3)),
+                     ("nrm", real, (8, 3)), ("pen", real, (8,)), ("qdf", real, (21,)), ("v0f", real, (6,)), ("dqd", real, (21,)),
+                     ("dv0", real, (6,)), ("active", np.int32, (8,)), ("stone", np.int32, (8,))])
+
+
 class Info(C.Structure):
     _fields_ = [("ep_ret", C.c_float), ("ep_len", C.c_float), ("bad_transition", C.c_int32),
                 ("steps_reached", C.c_int32), ("update_terrain", C.c_int32)]
@@ -46,6 +56,10 @@ def load(prec="f32"):
     lib.sso_reset.argtypes = [vp, vp]
     lib.sso_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.sso_step_margins.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.sso_step_near.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, i32]
+    lib.sso_step_forced.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32]
+    lib.sso_step_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, i32, vp, vp, i32]
+    lib.sso_debug_contact.argtypes = [vp, i32, vp, vp]
     lib.sso_set_curriculum.argtypes = [vp, i32]
     lib.sso_set_specialist.argtypes = [vp, i32]
     lib.sso_set_sample_prob.argtypes = [vp, vp, i32]
@@ -115,6 +129,66 @@ class OracleEnv:
         margins = np.zeros((self.n, 2), self.real)
         self.lib.sso_step_margins(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info), _p(margins))
         return obs, rew, done, info, margins
+
+    def _out(self):
+        return (np.zeros((self.n, OBS_DIM), np.float32), np.zeros(self.n, np.float32), np.zeros(self.n, np.uint8),
+                np.zeros(self.n, INFO_DTYPE))
+
+    def step_near(self, act, tol=1e-5, cap=NEAR_CAP):
+        """step_margins() that also lists the decisions within `tol` of their threshold: near [N,cap] (indices of the
+        decision sites in visiting order, -1 padded) and nnear [N] (their true number; > cap means the list is cut)."""
+        act = np.ascontiguousarray(act, np.float32).reshape(self.n, ACT_DIM)
+        obs, rew, done, info = self._out()
+        margins = np.zeros((self.n, 2), self.real)
+        near = np.full((self.n, cap), -1, np.int32)
+        nnear = np.zeros(self.n, np.int32)
+        self.lib.sso_step_near(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info), _p(margins), float(tol), _p(near),
+                               _p(nnear), int(cap))
+        return obs, rew, done, info, margins, near, nnear
+
+    def step_forced(self, act, force, nforce):
+        """step() with, per env, the outcome of the decisions force[e, :nforce[e]] inverted (the other branch of a
+        near-threshold decision)."""
+        act = np.ascontiguousarray(act, np.float32).reshape(self.n, ACT_DIM)
+        force = np.ascontiguousarray(force, np.int32).reshape(self.n, -1)
+        nforce = np.ascontiguousarray(nforce, np.int32).reshape(self.n)
+        obs, rew, done, info = self._out()
+        self.lib.sso_step_forced(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info), _p(force), _p(nforce), force.shape[1])
+        return obs, rew, done, info
+
+    def step_ex(self, act, tol=None, cap=NEAR_CAP, force=None, nforce=None, record=False, replay=None):
+        """The general step: returns a dict with obs / rew / done / info and, on request, `margins` [N,2] + `near`
+        [N,cap] + `nnear` [N] (tol given: decisions within tol of their threshold), `trace` [N,MAX_DECISIONS] uint8
+        (record=True: the outcome of every decision).  force / nforce invert the listed decisions; replay (a trace)
+        freezes every decision to the recorded outcome."""
+        act = np.ascontiguousarray(act, np.float32).reshape(self.n, ACT_DIM)
+        obs, rew, done, info = self._out()
+        out = dict(obs=obs, rew=rew, done=done, info=info)
+        margins = near = nnear = trace = None
+        if tol is not None:
+            margins = out["margins"] = np.zeros((self.n, 2), self.real)
+            near = out["near"] = np.full((self.n, cap), -1, np.int32)
+            nnear = out["nnear"] = np.zeros(self.n, np.int32)
+        if force is not None:
+            force = np.ascontiguousarray(force, np.int32).reshape(self.n, cap)
+            nforce = np.ascontiguousarray(nforce, np.int32).reshape(self.n)
+        if record:
+            trace = out["trace"] = np.zeros((self.n, MAX_DECISIONS), np.uint8)
+        if replay is not None:
+            replay = np.ascontiguousarray(replay, np.uint8).reshape(self.n, MAX_DECISIONS)
+        nul = lambda a: _p(a) if a is not None else None
+        self.lib.sso_step_ex(self.h, _p(act), _p(obs), _p(rew), _p(done), _p(info), nul(margins), float(tol or 0.0), nul(near),
+                             nul(nnear), nul(force), nul(nforce), int(cap), nul(trace), nul(replay), MAX_DECISIONS)
+        return out
+
+    def debug_contact(self, e, tau):
+        """ONE substep of env e under fixed motor torques (the env's state advances); returns the contact stage's
+        intermediate quantities as a dict of arrays (oracle/ss_oracle.c: contact_tap)."""
+        tau = np.ascontiguousarray(tau, self.real)
+        tap = np.zeros(1, tap_dtype(self.real))
+        assert tap.nbytes == self.lib.sso_tap_size()
+        self.lib.sso_debug_contact(self.h, int(e), _p(tau), _p(tap))
+        return {k: tap[k][0].copy() for k in tap.dtype.names}
 
     def set_curriculum(self, c):
         self.lib.sso_set_curriculum(self.h, int(c))

@@ -1,0 +1,212 @@
+"""The parity rule of the GPU tests: how ONE control step of the HIP path, started from an injected state, is judged
+against the CPU oracle.  TEST INFRASTRUCTURE (imports oracle_lib).
+
+Every env-step is bounded -- none passes on an allowance:
+
+  integers (next_step_index, counters, RNG counter, contact flags, done, bad_transition, update_terrain): bit-exact;
+  observation: |obs_hip - obs_oracle| <= max(1e-4, 6 s)      (1e-4 = the north-star's per-step bound)
+  reward:      |rew_hip - rew_oracle| <= max(1e-3, 6 s_rew)
+
+where s is the MEASURED first-order sensitivity of that very env-step in the fp64 build of the oracle: each of the 55
+dynamic state inputs (base pose / twist, q, qd) is perturbed by 8 ulp (relative 8 * 2^-23, floor 1e-3 absolute scale), one
+at a time, and the absolute changes of the observation are summed per component (a first-order worst case over the
+signs of the input errors); s also includes the distance between the oracle's own fp32 and fp64 builds on that step.  An
+env-step with 6 s <= 1e-4 is "plain" and held to the north-star's 1e-4; one with 6 s > 1e-4 ("sensitive": the light
+foot / ankle pivoting on one or two sole corners amplifies rounding 1e2..1e5 x within the four substeps, measured on the
+CPU alone) is held to 6 x what the specification itself does to an 8-ulp input error.  The classification never looks at
+the HIP result.  Calibration (163 840 env-steps, both robots, flat and curriculum-5 terrain, round-3 kernels): the largest
+|obs| error over s is 3.7; the largest error of a plain env-step is 5e-5; 64 % of env-steps are plain, the median bound of
+the others is 2e-4.  The fp32 oracle itself is farther than 1e-4 from its fp64 build on 0.16 % of env-steps (the kernel:
+0.17 %), so no fp32 implementation can hold 1e-4 on every step -- hence a bound that scales with the step's own
+conditioning rather than a blanket allowance.
+
+  decisions: when a discrete decision of the oracle's step (contact predicate of a sole corner, winner among two stones,
+  joint-limit switch, reward / done thresholds) lies within 1e-5 of its threshold, an fp32 implementation with another
+  operation order may take the other branch.  Then the HIP result must agree -- integers exactly, observation / reward
+  to the bounds above -- with the oracle re-evaluated with SOME subset of the near-threshold decisions inverted
+  (oracle_lib.step_ex(force=...); decisions that become near-threshold on the alternative trajectory are searched too,
+  depth <= 3); the sensitivity along an alternative branch is measured with every decision frozen (replay) so that the
+  probe cannot flip the branch it is measuring.
+
+`StepJudge.judge()` returns per-env arrays; `category`: 0 plain, 1 sensitive, 2 other branch, 3 other branch + sensitive.
+"""
+import numpy as np
+
+import oracle_lib as ol
+
+OBS_TOL, REW_TOL, NEAR_TOL = 1e-4, 1e-3, 1e-5
+ULPS, SENS_FACTOR = 8.0, 6.0
+MAX_DEPTH, MAX_ALTERNATIVES = 3, 24
+NDYN = 55                                   # pos 3, quat 4, twist 6, q 21, qd 21 of the packed state
+INT_FIELDS = [ol.S_N, ol.S_COUNT, ol.S_ELAPSED, ol.S_CTRLO, ol.S_CTRHI, ol.S_FLAGS]
+
+
+def _ints(state, done, info):
+    """[N, 9] integer outcome of a step: the six integer state fields, done, bad_transition, update_terrain."""
+    return np.concatenate([state[:, INT_FIELDS].astype(np.int64), np.asarray(done).astype(np.int64)[:, None],
+                           np.asarray(info["bad_transition"]).astype(np.int64)[:, None],
+                           np.asarray(info["update_terrain"]).astype(np.int64)[:, None]], axis=1)
+
+
+class StepJudge:
+    def __init__(self, kind, n, seed=0, env_offset=0, curriculum=0, setup=None):
+        self.n = n
+        self.o32 = ol.OracleEnv(kind, n, seed=seed, env_offset=env_offset)
+        self.alt = ol.OracleEnv(kind, n, seed=seed, env_offset=env_offset)
+        self.o64 = ol.OracleEnv(kind, n, seed=seed, env_offset=env_offset, prec="f64")
+        for o in (self.o32, self.alt, self.o64):
+            if curriculum:
+                o.set_curriculum(curriculum)
+            if setup:
+                setup(o)
+            o.reset()
+
+    # ------------------------------------------------------------------------------------------------ sensitivity
+    def _sensitivity(self, st64, act, ref, replay=None):
+        """Sum over the 55 dynamic inputs of |change of obs| (per component, then max) and of |change of rew| under an
+        8-ulp perturbation of that input, in the fp64 oracle; `stable`: no perturbation changed an integer outcome."""
+        acc_o = np.zeros((self.n, ol.OBS_DIM))
+        acc_r = np.zeros(self.n)
+        stable = np.ones(self.n, bool)
+        for i in range(NDYN):
+            p = st64.copy()
+            p[:, i] += ULPS * 2.0 ** -23 * np.maximum(np.abs(p[:, i]), 1e-3)
+            self.o64.set_state(p)
+            r = self.o64.step_ex(act, replay=replay)
+            acc_o += np.abs(r["obs"].astype(np.float64) - ref["obs"])
+            acc_r += np.abs(r["rew"].astype(np.float64) - ref["rew"])
+            if replay is None:
+                stable &= (_ints(self.o64.get_state(), r["done"], r["info"]) == ref["ints"]).all(axis=1)
+        return acc_o.max(axis=1), acc_r, stable
+
+    # ------------------------------------------------------------------------------------------------ the rule
+    def judge(self, st, act, g_obs, g_rew, g_done, g_state, g_bad, g_upd):
+        """st [N,185] f32 injected state, act [N,21]; g_*: what the HIP path returned for that step (g_state: its packed
+        state after the step).  Leaves self.o32 advanced by the step (self.o32.get_state() is the next state)."""
+        n = self.n
+        st = np.ascontiguousarray(st, np.float32)
+        st64 = st.astype(np.float64)
+        g_obs = np.asarray(g_obs, np.float64)
+        g_rew = np.asarray(g_rew, np.float64)
+        g_int = _ints(np.asarray(g_state), g_done, dict(bad_transition=g_bad, update_terrain=g_upd))
+        self.o32.set_state(st)
+        b = self.o32.step_ex(act, tol=NEAR_TOL, record=True)
+        so = self.o32.get_state()
+        b_int = _ints(so, b["done"], b["info"])
+        self.o64.set_state(st64)
+        r64 = self.o64.step_ex(act)
+        ref = dict(obs=r64["obs"].astype(np.float64), rew=r64["rew"].astype(np.float64),
+                   ints=_ints(self.o64.get_state(), r64["done"], r64["info"]))
+        s_obs, s_rew, stable = self._sensitivity(st64, act, ref)
+        s_obs = np.maximum(s_obs, np.abs(b["obs"] - ref["obs"]).max(axis=1))
+        s_rew = np.maximum(s_rew, np.abs(b["rew"] - ref["rew"]))
+        tol_o = np.maximum(OBS_TOL, SENS_FACTOR * s_obs)
+        tol_r = np.maximum(REW_TOL, SENS_FACTOR * s_rew)
+        e_obs = np.abs(g_obs - b["obs"]).max(axis=1)
+        e_rew = np.abs(g_rew - b["rew"])
+        int_ok = (g_int == b_int).all(axis=1)
+        near = b["nnear"] > 0
+        category = np.where(SENS_FACTOR * s_obs > OBS_TOL, 1, 0)
+        # plain / sensitive env-steps: the oracle as it ran.  An integer mismatch is accepted only where the probe itself
+        # saw an 8-ulp input error change an integer outcome (counted by the callers, must stay rare)
+        ok = (e_obs <= tol_o) & (e_rew <= tol_r) & (int_ok | ~stable)
+        matched_e = e_obs.copy()
+        int_excused = ~int_ok & ~stable & ~near
+        if near.any():
+            self._branches(st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o)
+        return dict(ok=ok, e_obs=e_obs, e_rew=e_rew, matched_e=matched_e, tol=tol_o, s=s_obs, category=category, near=near,
+                    int_ok=int_ok, int_excused=int_excused, e_o32_o64=np.abs(b["obs"] - ref["obs"]).max(axis=1),
+                    oracle=b, next_state=so)
+
+    def _branches(self, st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o):
+        """Env-steps with a near-threshold decision: search the alternative branches (module docstring)."""
+        n, cap = self.n, ol.NEAR_CAP
+        envs = np.nonzero(near)[0]
+        # per env: queue of forced sets still to evaluate, the sets seen, the closest integer-exact branch so far
+        queue = {e: [(int(i),) for i in b["near"][e, :min(b["nnear"][e], cap)]] for e in envs}
+        seen = {e: set(queue[e]) | {()} for e in envs}
+        best, resolved = {}, {}
+        for e in envs:
+            same_int = bool((g_int[e] == b_int[e]).all())
+            best[e] = (matched_e[e] if same_int else np.inf, ())
+            resolved[e] = same_int and matched_e[e] <= OBS_TOL and e_rew[e] <= REW_TOL     # the branch the oracle took
+            ok[e] = resolved[e]
+            category[e] = 0
+        done_runs = {e: 0 for e in envs}
+        while True:
+            todo = [e for e in envs if not resolved[e] and queue[e] and done_runs[e] < MAX_ALTERNATIVES]
+            if not todo:
+                break
+            force = np.zeros((n, cap), np.int32)
+            nforce = np.zeros(n, np.int32)
+            cur = {}
+            for e in todo:
+                S = queue[e].pop(0)
+                cur[e] = S
+                force[e, :len(S)] = S
+                nforce[e] = len(S)
+                done_runs[e] += 1
+            self.alt.set_state(st)
+            r = self.alt.step_ex(act, tol=NEAR_TOL, force=force, nforce=nforce)
+            a_int = _ints(self.alt.get_state(), r["done"], r["info"])
+            for e in todo:
+                S = cur[e]
+                ea = np.abs(g_obs[e] - r["obs"][e]).max()
+                er = abs(g_rew[e] - r["rew"][e])
+                same_int = (g_int[e] == a_int[e]).all()
+                if same_int and ea < best[e][0]:
+                    best[e] = (ea, S)
+                if same_int and ea <= OBS_TOL and er <= REW_TOL:
+                    resolved[e] = True
+                    ok[e] = True
+                    matched_e[e] = ea
+                    category[e] = 2
+                    continue
+                if len(S) < MAX_DEPTH:
+                    for i in r["near"][e, :min(r["nnear"][e], cap)]:
+                        T = tuple(sorted(set(S) | {int(i)}))
+                        if T not in seen[e]:
+                            seen[e].add(T)
+                            queue[e].append(T)
+        # what is left: the closest integer-exact branch, held to its own frozen-decision sensitivity
+        left = [e for e in envs if not resolved[e] and np.isfinite(best[e][0])]
+        if left:
+            force = np.zeros((n, cap), np.int32)
+            nforce = np.zeros(n, np.int32)
+            for e in left:
+                S = best[e][1]
+                force[e, :len(S)] = S
+                nforce[e] = len(S)
+            self.alt.set_state(st)
+            ra = self.alt.step_ex(act, force=force, nforce=nforce, record=True)
+            self.o64.set_state(st64)
+            r6 = self.o64.step_ex(act, replay=ra["trace"])
+            ref = dict(obs=r6["obs"].astype(np.float64), rew=r6["rew"].astype(np.float64), ints=None)
+            s_o, s_r, _ = self._sensitivity(st64, act, ref, replay=ra["trace"])
+            s_o = np.maximum(s_o, np.abs(ra["obs"] - ref["obs"]).max(axis=1))
+            s_r = np.maximum(s_r, np.abs(ra["rew"] - ref["rew"]))
+            for e in left:
+                ea = np.abs(g_obs[e] - ra["obs"][e]).max()
+                er = abs(g_rew[e] - ra["rew"][e])
+                lim_o, lim_r = max(OBS_TOL, SENS_FACTOR * s_o[e]), max(REW_TOL, SENS_FACTOR * s_r[e])
+                ok[e] = bool(ea <= lim_o and er <= lim_r)
+                matched_e[e] = ea
+                tol_o[e] = lim_o
+                category[e] = 3 if len(best[e][1]) else 1
+        for e in envs:
+            if not resolved[e] and not np.isfinite(best[e][0]):
+                ok[e] = False
+
+
+def summarize(results):
+    """Concatenate the per-step dicts of judge() and return (arrays, text)."""
+    keys = ("ok", "e_obs", "e_rew", "matched_e", "tol", "s", "category", "near", "int_ok", "int_excused", "e_o32_o64")
+    r = {k: np.concatenate([x[k] for x in results]) for k in keys}
+    cat = r["category"]
+    plain = cat == 0
+    txt = ("%d env-steps: %d plain (max |obs| err %.2e, bound 1e-4), %d sensitive (max err / bound %.2f), %d matched another "
+           "branch, %d another branch + sensitive; integer mismatches excused by an unstable probe: %d; failures: %d" % (
+               cat.size, plain.sum(), r["matched_e"][plain].max() if plain.any() else 0.0, (cat == 1).sum(),
+               (r["matched_e"] / r["tol"])[cat == 1].max() if (cat == 1).any() else 0.0, (cat == 2).sum(), (cat == 3).sum(),
+               r["int_excused"].sum(), (~r["ok"]).sum()))
+    return r, txt

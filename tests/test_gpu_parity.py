@@ -1,20 +1,16 @@
 """GPU parity tests: the HIP path (through the C ABI, via steppingstone_amd.envs) against the CPU oracle on the
 same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
 
-Tolerances (fp32, stated here as required by the task brief):
-  * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, done,
-    bad_transition, update_terrain): bit-exact;
+Tolerances (fp32, stated here as required by the task brief; the rule itself is tests/parity_rule.py):
+  * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, contact flags,
+    done, bad_transition, update_terrain): bit-exact;
   * one control step from an identical injected state (4 substeps, different operation order, own sincos / reciprocal):
-    every env-step is CLASSIFIED with the oracle itself --
-      flagged   = a state-affecting discrete decision of that step (contact predicate of a sole corner, stone choice,
-                  joint-limit switch; oracle_lib.step_margins) lies within 1e-5 of its threshold, OR the fp32 and the
-                  fp64 build of the oracle's own C code disagree by more than 2.5e-5 on that very step (the step
-                  amplifies fp32 rounding >= 50x: ill-conditioned contact solve);
-      unflagged = everything else (measured 97 % of env-steps): integers bit-exact, |obs| error <= 5e-4 for ALL of
-                  them and <= 1e-4 (the north-star's bound) for >= 99.95 % (measured 99.98 %, 99.9 % within 4e-5),
-                  reward <= 1e-3, state <= 2.5e-3 relative;
-    flagged env-steps (<= 5 %) may take the other branch -- they are counted and reported, and an integer / done
-    mismatch is accepted only on a flagged step (tools/parity_margins.py prints the full table);
+    EVERY env-step is bounded by |obs| error <= max(1e-4, 6 s), |rew| error <= max(1e-3, 6 s_rew), where 1e-4 is the
+    north-star's per-step bound and s is the measured first-order response of the fp64 oracle to an 8-ulp error in
+    each of that step's 55 dynamic state inputs (summed); an env-step whose oracle evaluation has a discrete decision
+    within 1e-5 of its threshold must match the oracle re-evaluated on one of the alternative branches (integers
+    exactly).  No env-step passes on an allowance; integer mismatches are accepted nowhere except where the 8-ulp
+    probe itself changes an integer outcome (asserted < 0.1 % of env-steps, measured 0);
   * free-running drift is chaotic (contacts make/break): characterised against the fp64 build, see
     tests/test_gpu_branches.py::test_closed_loop_1000_step_drift.
 """
@@ -23,6 +19,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+import parity_rule as pr
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -65,64 +62,69 @@ def test_random_action_stream_is_bit_exact():
     g.close()
 
 
-def _step_parity(env_id, kind, n, steps, seed, curriculum=0):
-    """One control step from identical injected states: HIP kernel vs fp32 oracle, with the fp64 oracle and the
-    oracle's decision margins as the classifier (module docstring).  Returns the per-env-step arrays."""
-    g = gpu_env(env_id, n, seed=seed)
-    o = ol.OracleEnv(kind, n, seed=seed)
-    o64 = ol.OracleEnv(kind, n, seed=seed, prec="f64")
+def _judged_steps(env_id, kind, n, steps, seed, curriculum=0, on_device_actions=False, burn_in=0):
+    """`steps` single control steps from identical injected states, HIP kernel vs oracle, every env-step judged by
+    parity_rule.StepJudge.  on_device_actions: the step is ss_rollout_random(1 step at t) -- the benchmarked kernel
+    instantiation with its own Philox actions -- instead of ss_step with the oracle's action array."""
+    if on_device_actions:
+        from steppingstone_amd.envs import SteppingStoneVecEnv
+        g = SteppingStoneVecEnv(env_id, n, seed=seed, device="cuda:0", return_numpy=False)
+    else:
+        g = gpu_env(env_id, n, seed=seed)
+    J = pr.StepJudge(kind, n, seed=seed, curriculum=curriculum)
     if curriculum:
         g.update_curriculum(curriculum)
-        o.set_curriculum(curriculum)
-        o64.set_curriculum(curriculum)
     g.reset()
-    o.reset()
-    o64.reset()
-    rows = {k: [] for k in ("e_obs", "e_state", "e_rew", "ints", "flag")}
-    for t in range(steps):
-        st = o.get_state()
+    for t in range(burn_in):                       # diverse states (falls, partial contacts, resets) before the judged steps
+        J.o32.step(J.o32.random_actions(t))
+    st = J.o32.get_state()
+    res = []
+    for t in range(burn_in, burn_in + steps):
         g.set_state(st)
-        o64.set_state(st.astype(np.float64))
-        a = o.random_actions(t)
-        o6 = o64.step(a)[0]
-        oo, ro, do, io, mg = o.step_margins(a)
-        og, rg, dg, ig = g.step(a)
-        sg, so = g.get_state().cpu().numpy(), o.get_state()
+        a = J.o32.random_actions(t)
+        if on_device_actions:
+            og, rg, dg = [x.cpu().numpy() for x in g.rollout_random(1, t0=t, steps_per_launch=1)]
+        else:
+            og, rg, dg, _ = g.step(a)
+        sg = g.get_state().cpu().numpy()
         raw = g._info.cpu().numpy()
-        cont = ~do.astype(bool)                                   # a finished env's state is the fresh reset state
-        rows["e_obs"].append(np.abs(og - oo).max(axis=1))
-        rows["e_state"].append(np.where(cont, (np.abs(sg[:, :59] - so[:, :59]) / (1.0 + np.abs(so[:, :59]))).max(axis=1), 0.0))
-        rows["e_rew"].append(np.abs(rg - ro))
-        rows["ints"].append((sg[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1) & (dg == do.astype(bool)) &
-                            (raw[:, 2] == io["bad_transition"]) & (raw[:, 4] == io["update_terrain"]))
-        rows["flag"].append((mg[:, 0] < 1e-5) | (np.abs(oo - o6).max(axis=1) > 2.5e-5))
+        r = J.judge(st, a, og, rg, dg.astype(bool), sg, raw[:, 2], raw[:, 4])
+        res.append(r)
+        st = r["next_state"]
     g.close()
-    return {k: np.concatenate(v) for k, v in rows.items()}
+    return pr.summarize(res)
+
+
+def _assert_judged(R, txt, label):
+    print("%s: %s" % (label, txt))
+    print("   bound quantiles over env-steps 50/90/99/100 %%: %s ; |hip - oracle| quantiles: %s" % (
+        np.array2string(np.quantile(R["tol"], [.5, .9, .99, 1.0]), precision=2), np.array2string(np.quantile(R["e_obs"], [.5, .9, .99, 1.0]), precision=2)))
+    assert R["ok"].all(), "%d env-steps outside their bound" % (~R["ok"]).sum()
+    plain = R["category"] == 0
+    assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 6 s <= 1e-4
+    assert R["int_excused"].mean() < 1e-3
+    assert np.quantile(R["e_obs"], 0.99) < 1e-4                                      # all env-steps, against the oracle as it ran
 
 
 @pytest.mark.parametrize("env_id,kind", KINDS)
 def test_single_step_parity_from_injected_state(env_id, kind):
-    r = _step_parity(env_id, kind, n=256, steps=60, seed=11)
-    u = ~r["flag"]
-    print("single-step parity %s: %d env-steps, %.2f %% flagged (decision within 1e-5 of a threshold, or fp32-vs-fp64 oracle "
-          "disagreement > 2.5e-5); unflagged: max |obs| %.2e, > 1e-4: %d, max state rel %.2e, max |rew| %.2e; integer mismatches "
-          "(all on flagged steps): %d" % (kind, u.size, 100 * r["flag"].mean(), r["e_obs"][u].max(), (r["e_obs"][u] > 1e-4).sum(),
-                                          r["e_state"][u].max(), r["e_rew"][u].max(), (~r["ints"]).sum()))
-    assert r["flag"].mean() < 0.05
-    assert r["ints"][u].all(), "integer / done mismatch on an unflagged env-step"
-    assert r["e_obs"][u].max() < 5e-4 and (r["e_obs"][u] > 1e-4).mean() < 5e-4
-    assert r["e_rew"][u].max() < 1e-3 and r["e_state"][u].max() < 2.5e-3
-    assert np.quantile(r["e_obs"], 0.99) < 1e-4          # all env-steps, flagged ones included
+    R, txt = _judged_steps(env_id, kind, n=256, steps=60, seed=11)
+    _assert_judged(R, txt, "single-step parity %s, flat terrain" % kind)
 
 
 @pytest.mark.parametrize("env_id,kind", KINDS)
 def test_single_step_parity_on_curriculum_terrain(env_id, kind):
     """Same rule on tilted / turned stones (curriculum 5, grid drawn stones in play after the first resets)."""
-    r = _step_parity(env_id, kind, n=256, steps=40, seed=23, curriculum=5)
-    u = ~r["flag"]
-    assert r["flag"].mean() < 0.05 and r["ints"][u].all()
-    assert r["e_obs"][u].max() < 5e-4 and (r["e_obs"][u] > 1e-4).mean() < 5e-4
-    assert r["e_rew"][u].max() < 1e-3 and r["e_state"][u].max() < 2.5e-3
+    R, txt = _judged_steps(env_id, kind, n=256, steps=40, seed=23, curriculum=5)
+    _assert_judged(R, txt, "single-step parity %s, curriculum 5" % kind)
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_benchmarked_rollout_step_against_the_oracle_at_full_size(env_id, kind):
+    """BASELINE size, the benchmarked instantiation: ss_rollout_random(1 step at index t) -- on-device Philox actions --
+    against o.step(o.random_actions(t)) from injected states, 4096 envs, same rule (no chain through ss_step)."""
+    R, txt = _judged_steps(env_id, kind, n=4096, steps=3, seed=5, curriculum=5, on_device_actions=True, burn_in=25)
+    _assert_judged(R, txt, "rollout kernel %s, 4096 envs" % kind)
 
 
 def _stand_on_target(o, n_envs):
