@@ -438,6 +438,11 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
 static int g_pgs_iters = PGS_ITERS;
 static int g_pgs_warm = PGS_WARM;
 void sso_debug_set_solver(int iters, int warm) { g_pgs_iters = iters; g_pgs_warm = warm; }
+/* further knobs of the same study (tools/spec_deviations.py -> DESIGN.md section 3 table): Baumgarte factor, and
+ * Gauss-Seidel instead of Jacobi BETWEEN the feet (a row then sees the other foot's impulses of the same sweep) */
+static real g_erp = ERP;
+static int g_seq_feet = 0;
+void sso_debug_set_variant(double erp, int seq_feet) { g_erp = (real)erp; g_seq_feet = seq_feet; }
 
 typedef struct { real lam[8][3]; int stone[8]; } warm_state;   /* impulses of the previous substep of this step */
 
@@ -503,7 +508,7 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     }
     real corr = c->pen - SLOP;
     if (corr < 0) corr = 0;
-    bn[k] = ERP * corr / H_SUB;
+    bn[k] = g_erp * corr / H_SUB;
     if (bn[k] > VCORR_MAX) bn[k] = VCORR_MAX;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
   }
@@ -542,6 +547,7 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
           V[f * 6 + i] += y[f * 6 + i] * dl;          /* own foot: immediately (also tracked in Vnext) */
           Vnext[f * 6 + i] += y[f * 6 + i] * dl;
           Vnext[g * 6 + i] += y[g * 6 + i] * dl;      /* other foot: visible from the next sweep on */
+          if (g_seq_feet) V[g * 6 + i] += y[g * 6 + i] * dl;   /* (study variant: visible at once) */
         }
       }
     }
