@@ -56,16 +56,33 @@ def latest_profile(pattern):
     return files[-1] if files else None
 
 
-def recorded_traffic(n_envs, tag):
-    """HBM bytes per launch of the dominant kernel from the latest committed PMC run (separate FETCH_SIZE / WRITE_SIZE
-    passes, calibrated on a dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py).  PMC collection
-    needs rocprofv3 around the process, so bench.py reports the recorded figure and names its source; null if absent."""
-    f = latest_profile("*hbm_traffic_%s%d.json" % (tag, n_envs))
-    if not f:
-        return None, None, None
-    with open(f) as fh:
-        d = json.load(fh)
-    return float(d["hbm_bytes_per_env_step"]) * n_envs, os.path.relpath(f, ROOT), d       # bytes per control step of the batch
+def traffic_model(n_envs):
+    """HBM bytes per launch of the dominant kernel as a function of the control steps in the launch, from the two latest
+    committed PMC runs of that kernel at this batch size (separate FETCH_SIZE / WRITE_SIZE passes, calibrated on a
+    dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py): a 1-step launch and an S-step launch (S = 250)
+    give  bytes(launch of k steps) = const + per_step * k.  The traffic is almost a per-launch constant (state in once,
+    dirty lines out once; the per-step rows are overwritten in L2), so a per-env-step figure recorded at one launch length
+    must not be scaled linearly to another.  PMC collection needs rocprofv3 around the process, so bench.py reports the
+    model and names its sources; (None, None) if a file is missing."""
+    f1, fs = latest_profile("*hbm_traffic_%d.json" % n_envs), latest_profile("*hbm_traffic_rollout_%d.json" % n_envs)
+    if not f1 or not fs:
+        return None, None
+    with open(f1) as fh:
+        d1 = json.load(fh)
+    with open(fs) as fh:
+        ds = json.load(fh)
+    s1, ss = float(d1.get("steps_per_launch", 1)), float(ds["steps_per_launch"])
+    b1, bs = float(d1["hbm_bytes_per_launch"]), float(ds["hbm_bytes_per_launch"])
+    if ss <= s1:
+        return None, None
+    per_step = (bs - b1) / (ss - s1)
+    const = b1 - per_step * s1
+    info = {"bytes_per_launch_const": const, "bytes_per_step": per_step,
+            "fitted_from": [{"file": os.path.relpath(f1, ROOT), "steps_per_launch": s1, "bytes_per_launch": b1},
+                            {"file": os.path.relpath(fs, ROOT), "steps_per_launch": ss, "bytes_per_launch": bs}],
+            "note": "1-step launches are the step kernel, S-step launches the rollout kernel (same step_env code, state resident in "
+                    "LDS between the steps)"}
+    return (lambda k: const + per_step * k), info
 
 
 def recorded_pmc():
@@ -192,15 +209,19 @@ def cpu_baseline(budget=24.0):
     # C3 / C4: process-per-env shared-memory front end, P = min(cores, 64) workers
     workers = max(2, min(usable, 64))
     try:
+        if lib_path:
+            os.environ["SS_ORACLE_LIB_F32"] = lib_path            # the workers (spawned processes) load the same native build as C2
         v3, s3, t3 = sf.measure("walker3d", workers, seconds=0.2 * budget)
         out["shmem_frontend"] = {"value": v3, "cores": workers, "envs": workers, "steps": s3, "seconds": t3,
                                  "note": "one worker process per env, pipe + shared-memory obs (architecture of "
-                                         "common/envs_utils.py:486-675) around the parity-build oracle"}
+                                         "common/envs_utils.py:486-675) around the same oracle build as all_cores (%s)" % flags}
         v4, s4, t4 = sf.measure("noop", workers, seconds=0.1 * budget)
         out["ipc_only"] = {"value": v4, "cores": workers, "envs": workers, "steps": s4, "seconds": t4,
                            "note": "same front end, no-op env: ceiling of the process-per-env architecture on this host"}
     except Exception as exc:                                     # a baseline row must never fail the bench
         out["shmem_frontend"] = {"value": None, "error": repr(exc)[:200]}
+    finally:
+        os.environ.pop("SS_ORACLE_LIB_F32", None)
     return out
 
 
@@ -237,6 +258,10 @@ def main():
                     help="N>1: headline = one launch + one all-gather per step instead of 32-step chunks")
     ap.add_argument("--peer-store", action="store_true",
                     help="N>1: also time the peer-store exchange (steppingstone_amd/peer.py; validated on one GPU only so far)")
+    ap.add_argument("--ppo", action="store_true",
+                    help="BASELINE configs[4] instead of the rollout metric: PPO end to end (MikeStepperEnv-v0, curriculum on, 4096 "
+                         "envs per GPU, 32-step rollouts, actor/critic on PyTorch-ROCm), frames/s; --updates U")
+    ap.add_argument("--updates", type=int, default=10, help="--ppo: number of PPO updates (<= 10 keeps the run under two minutes)")
     ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
     args = ap.parse_args()
 
@@ -277,6 +302,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     n_local = args.envs_per_gpu
+    if args.ppo:
+        ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     local = SteppingStoneVecEnv(args.env, n_local, seed=0, device=dev, env_id_offset=rank * n_local, return_numpy=False)
     if args.curriculum:
         local.update_curriculum(args.curriculum)
@@ -318,12 +349,40 @@ def main():
     PREWARM = 256
     local.rollout_random(PREWARM, t0=1 << 20, steps_per_launch=PREWARM)
     sync()
+    def reduce_max(x):
+        if not use_dist:
+            return x
+        v = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
     if W:
         run(W, 0)
-    elapsed, main_ev_ms = timed(lambda: run(K, W))
+    # The timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  A region shorter than
+    # 50 ms (the driver runs --steps 20: 1 ms) is one noisy sample, so it is then repeated REPEATS times -- every repeat is
+    # again exactly K steps, continuing the rollout -- and the MEDIAN region is reported (min / max beside it).
+    REPEAT_BELOW_S, REPEATS = 0.05, 9
+    t_next = W
+    samples = []
+    for rep in range(REPEATS):
+        el, ev = timed(lambda: run(K, t_next))
+        t_next += K
+        samples.append((reduce_max(el), ev))
+        if rep == 0 and samples[0][0] >= REPEAT_BELOW_S:
+            break
+    order = sorted(range(len(samples)), key=lambda i: samples[i][0])
+    elapsed, main_ev_ms = samples[order[len(order) // 2]]
+    elapsed_min, elapsed_max = samples[order[0]][0], samples[order[-1]][0]
+    # self-proof of the exchange, straight after the headline run: every rank checksums its own block and each peer's block
+    # as received, the checksums are compared across ranks (ShardedVecEnv.verify_last_exchange)
+    gather_verified = None
+    if use_dist and gather:
+        try:
+            gather_verified, _ = env.verify_last_exchange()
+        except Exception as exc:
+            gather_verified = "error: " + repr(exc)[:200]
     # the other launch granularity / the collective-free pass, on the same K steps (not the headline value)
     side = {}
-    t_next = W + K
     if multi_step:
         el1, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=1))
         side["per_step_launch"] = {"ms_per_step": 1e3 * el1 / K, "value": n_local * K / el1, "kernel_ms": ev1 / K,
@@ -331,19 +390,28 @@ def main():
                                            "loop caller and the multi-GPU all-gather use)"}
         kernel_ms_per_step = main_ev_ms / K
     else:
+        def side_row(key, fn, note):
+            # a side row never takes the headline down with it; every rank runs the same rows in the same order
+            nonlocal t_next
+            try:
+                el, _ = timed(fn)
+                side[key] = {"ms_per_step": 1e3 * el / K, "note": note}
+            except Exception as exc:
+                side[key] = {"ms_per_step": None, "error": repr(exc)[:300]}
+            t_next += K
+
         if use_dist and gather:
             if chunked:
-                el2, _ = timed(lambda: env.rollout_random_chunked(K, t0=t_next, gather=False))
-                side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps, same 32-step launches, no collective"}
-                t_next += K
-                el4, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=True))
-                side["per_step_gather"] = {"ms_per_step": 1e3 * el4 / K,
-                                           "note": "one kernel launch and one all-gather of [N/G,62] per control step"}
-                t_next += K
+                side_row("no_gather", lambda: env.rollout_random_chunked(K, t0=t_next, gather=False),
+                         "same K steps, same 32-step launches, no collective")
+                side_row("per_step_gather", lambda: env.rollout_random(K, t0=t_next, gather=True),
+                         "one kernel launch and one all-gather of [N/G,62] per control step: SURVEY 8d-4's exchange as a "
+                         "policy-in-the-loop caller pays it (playground/train.py:373 consumes every step)")
             else:
-                el2, _ = timed(lambda: env.rollout_random(K, t0=t_next, gather=False))
-                side["no_gather"] = {"ms_per_step": 1e3 * el2 / K, "note": "same K steps without the per-step all-gather"}
-                t_next += K
+                side_row("no_gather", lambda: env.rollout_random(K, t0=t_next, gather=False),
+                         "same K steps without the per-step all-gather")
+                side_row("chunked_gather", lambda: env.rollout_random_chunked(K, t0=t_next, gather=True),
+                         "32 control steps per launch, one all-gather per chunk")
             if args.peer_store:
                 # the same exchange written by the step kernel itself into every peer's gather buffer (no collective in
                 # the data path; steppingstone_amd/peer.py).  A side row: a failure here never touches the headline value.
@@ -366,16 +434,14 @@ def main():
         _, ev1 = timed(lambda: local.rollout_random(K, t0=t_next, steps_per_launch=kspl))
         kernel_ms_per_step = ev1 / K                       # back-to-back launches on one stream: sum of durations
 
-    t = torch.tensor([elapsed, side.get("no_gather", {}).get("ms_per_step", 0.0),
-                      side.get("peer_store", {}).get("ms_per_step") or 0.0,
-                      side.get("per_step_gather", {}).get("ms_per_step", 0.0)], dtype=torch.float64, device=dev)
-    if use_dist:
+    keys = [k for k in ("no_gather", "per_step_gather", "chunked_gather", "peer_store") if side.get(k, {}).get("ms_per_step")]
+    if use_dist and keys:
+        t = torch.tensor([side[k]["ms_per_step"] for k in keys], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0].item())
-    for i, key in ((1, "no_gather"), (2, "peer_store"), (3, "per_step_gather")):
-        if key in side and side[key].get("ms_per_step"):
-            side[key]["ms_per_step"] = float(t[i].item())
-            side[key]["value"] = n_local * world / (side[key]["ms_per_step"] * 1e-3)
+        for i, k in enumerate(keys):
+            side[k]["ms_per_step"] = float(t[i].item())
+    for k in keys:
+        side[k]["value"] = n_local * world / (side[k]["ms_per_step"] * 1e-3)
 
     if rank == 0:
         total_envs = n_local * world
@@ -390,9 +456,8 @@ def main():
         algo_per_launch = algo_per_env_step * n_local * steps_in_launch
         achieved = algo_per_launch / (launch_ms * 1e-3) / 1e9
         tag = "rollout_" if (multi_step or chunked) else ""
-        traffic, traffic_src, traffic_rec = recorded_traffic(n_local, tag)
-        if traffic is not None:
-            traffic *= steps_in_launch                 # per launch of THIS run, like `achieved` (recorded per env-step)
+        tmodel, tinfo = traffic_model(n_local)
+        traffic = tmodel(steps_in_launch) if tmodel else None      # per launch of THIS run's launch shape, like `achieved`
         pmc, pmc_src = recorded_pmc()
         helpers = 3 if n_local <= 8192 else (1 if n_local <= 16384 else 0)
         model = "ModelWalker3D" if "Walker3D" in args.env else "ModelMike"
@@ -403,7 +468,8 @@ def main():
         out = {
             "metric": "env-steps/sec (batched random-action rollout)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / K, "repeats": len(samples), "ms_per_step_min": 1e3 * elapsed_min / K,
+            "ms_per_step_max": 1e3 * elapsed_max / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %d envs per MI355X, curriculum %d%s, on-device Philox U(-1,1) actions, auto-reset on"
                                    % (args.env, n_local, args.curriculum, " (flat terrain)" if not args.curriculum else ""),
@@ -412,13 +478,15 @@ def main():
                        "ranks": world, "collective": ((("%s all_gather_into_tensor of [32,%%d,62] f32 per 32-step chunk, %%d ranks"
                                                         if chunked else "%s all_gather_into_tensor of [%%d,62] f32 per step, %%d ranks")
                                                        % (test_transport or "RCCL")) % (n_local, world)) if gather else None,
+                       "value_is": ("K-step launches of the rollout kernel (state resident in LDS between steps)" if multi_step else
+                                    "32-step launches + one all-gather per 32-step chunk" if (chunked and gather) else
+                                    "one launch%s per control step" % (" + one all-gather" if gather else "")),
                        "steps_per_launch": steps_in_launch, "prewarm_steps": PREWARM,
                        **({"test_transport": "%s, all ranks on ONE GPU: a functional run of the N > 1 path, not a measurement" % test_transport}
                           if test_transport else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
-                         "traffic_source": traffic_src,
-                         "traffic_recorded_at_steps_per_launch": (traffic_rec or {}).get("steps_per_launch", 1 if traffic_rec else None),
+                         "traffic_model": tinfo,
                          "kernel": kernel, "kernel_ms": launch_ms, "kernel_ms_per_step": kernel_ms_per_step,
                          **launch_shape(W, K, steps_in_launch, kernel_ms_per_step),
                          "algorithmic_bytes_per_env_step": algo_per_env_step,
@@ -427,6 +495,22 @@ def main():
                          "note": pmc_note(pmc), "note_source": pmc_src},
         }
         out.update(side)
+        # the figure a policy-in-the-loop caller gets (one launch -- and at N > 1 one all-gather -- per control step), with the
+        # same prominence as `value` (the reference's loop consumes every step: playground/train.py:373)
+        pil = side.get("per_step_launch") or side.get("per_step_gather") or (
+            {"ms_per_step": 1e3 * elapsed / K, "value": value} if not (multi_step or chunked) else None)
+        if pil and pil.get("ms_per_step"):
+            out["policy_in_the_loop"] = {"value": pil.get("value", total_envs / (pil["ms_per_step"] * 1e-3)), "unit": "env-steps/s",
+                                         "ms_per_step": pil["ms_per_step"],
+                                         "what": "one kernel launch%s per control step" % (" + one RCCL all-gather of [N/G,62]" if gather else "")}
+        if use_dist:
+            out["gather_verified"] = gather_verified
+            out["rccl_ranks"] = dist.get_world_size()
+            try:
+                out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                out["rccl_version"] = None
+            out["transport"] = test_transport or "nccl (RCCL)"
         flop = None
         if pmc and pmc.get("per_wave_per_launch", {}).get("SQ_INSTS_VALU_FLOPS_FP32"):
             # per-wavefront mean x wavefronts per launch (main + helper wavefronts) x 64 lanes, per env-step of the launch
@@ -446,6 +530,59 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
+    """BASELINE.json configs[4] as it words it: MikeStepperEnv-v0, curriculum sampler on, 4096 envs per MI355X, the loop of
+    playground/train.py:363-521 (32-step rollouts, GAE, 10 PPO epochs of minibatch 1024, exponential lr decay, fixed-order
+    curriculum gate) with the actor / critic on PyTorch-ROCm (learner "torch": autograd + torch.optim.Adam) as THE row, and the
+    opt-in hand-written learner kernels (learner "fused") as a labelled side row.  frames = env-steps collected; the value is
+    steady-state frames/s over the updates after the first three (graph capture / allocator warm-up), the whole-run figure
+    beside it.  One JSON line from rank 0."""
+    from steppingstone_amd import ppo
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    U, T, MB = max(5, args.updates), 32, 1024
+    rows = {}
+    for learner in ("torch", "fused"):
+        if learner == "fused" and world > 1 and os.environ.get("SS_BENCH_TEST_TRANSPORT"):
+            continue
+        envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n_local, seed=8, device=dev, env_id_offset=rank * n_local, return_numpy=False)
+        stamps = []
+
+        def log(st):
+            torch.cuda.synchronize(dev)
+            stamps.append((time.perf_counter(), st["total_num_steps"], st["mean_rew"], st["curriculum"]))
+        try:
+            torch.cuda.synchronize(dev)
+            if use_dist:
+                dist.barrier()
+            t0 = time.perf_counter()
+            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=MB, use_curriculum=True, log=log, learner=learner)
+            torch.cuda.synchronize(dev)
+            if use_dist:
+                dist.barrier()
+            t1 = time.perf_counter()
+            steady = (stamps[-1][1] - stamps[2][1]) / (stamps[-1][0] - stamps[2][0])
+            rows[learner] = {"value": steady, "unit": "frames/s", "whole_run_frames_per_s": stamps[-1][1] / (t1 - t0),
+                             "updates": U, "steady_state_updates": U - 3, "ms_per_update": 1e3 * (stamps[-1][0] - stamps[2][0]) / (U - 3),
+                             "mean_episode_return_first_last": [stamps[0][2], stamps[-1][2]], "curriculum_level_end": stamps[-1][3]}
+        except Exception as exc:
+            rows[learner] = {"value": None, "error": repr(exc)[:300]}
+        envs.close()
+    if rank == 0:
+        main = rows["torch"]
+        out = {"metric": "frames/sec (PPO end-to-end, BASELINE configs[4])", "value": main.get("value"), "unit": "frames/s",
+               "n_gpus": world, "steps": U, "warmup": 3, "ms_per_step": main.get("ms_per_update"), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "MikeStepperEnv-v0, %d envs per MI355X, fixed-order curriculum on, PPO: %d-step rollouts, 10 epochs, "
+                                      "minibatch %d, actor / critic (SoftsignActor + critic) on PyTorch-ROCm, hipGraph replay of rollout and "
+                                      "minibatch step at one rank, eager + gradient all-reduce at several" % (n_local, T, MB),
+                          "envs_total": n_local * world, "learner": "torch", "a_step_is": "one PPO update = %d frames" % (T * n_local * world),
+                          "parallelism": "data-parallel x%d" % world},
+               "learner_torch": main, "learner_fused_side_row": rows.get("fused"),
+               "note": "random-init weights, synthetic rollouts of the env itself; the value is the torch-learner row"}
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 def extra_rows(torch, SteppingStoneVecEnv, dev, flop):

@@ -32,7 +32,9 @@ extern "C" {
 #define SS_GRID 11        /* playground/train.py:132-133 (11x11 yaw x pitch grid, centre index 5) */
 #define SS_NCELL 121
 #define SS_NUM_STONES 20
-#define SS_STATE_DIM 185  /* packed per-env state of ss_get_state / ss_set_state */
+#define SS_STATE_DIM 186  /* packed per-env state of ss_get_state / ss_set_state */
+#define SS_INFO_WORDS 6    /* 32-bit words of ss_info */
+#define SS_ABI_VERSION 3   /* ss_version(): 2 -> 3 added ss_info.ep_ret_lo and state word 185 (round 3) */
 #define SS_MAX_EPISODE_STEPS 1000
 
 typedef enum { SS_WALKER3D = 0, SS_MIKE = 1 } ss_kind;   /* ids: README.md:27,31 of the reference */
@@ -48,11 +50,15 @@ typedef enum {
 /* per-env step report; replaces the `info` dict built by Monitor.update (common/envs_utils.py:131-153) and
  * TimeLimitMask.step (:59-65) plus env.update_terrain (playground/train.py:245). ep_* valid when done. */
 typedef struct {
-  float ep_ret;            /* info["episode"]["r"] */
+  float ep_ret;            /* info["episode"]["r"], leading part (the fp32 nearest to the episode return) */
   float ep_len;            /* info["episode"]["l"] */
   int32_t bad_transition;  /* info["bad_transition"] */
   int32_t steps_reached;   /* next_step_index at the end of the step */
   int32_t update_terrain;  /* env.update_terrain */
+  /* Monitor.update sums the step rewards as Python floats and reports round(sum, 6) (common/envs_utils.py:131-138).  The
+   * kernel keeps the running sum as an unevaluated pair of floats (error-free two-sum per step):
+   * (double)ep_ret + (double)ep_ret_lo is the fp64 sum of the fp32 step rewards to ~1e-11; the host rounds it to 6 decimals. */
+  float ep_ret_lo;
 } ss_info;
 
 typedef struct ss_env ss_env;
@@ -140,13 +146,15 @@ int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens);
  *   0:3 pos | 3:7 quat wxyz | 7:13 base twist (body frame, angular first) | 13:34 q | 34:55 qd |
  *   55 pot_prev | 56 z_init | 57 ep_ret | 58 next-next dr | 59 next_step_index | 60 target_reached_count |
  *   61 elapsed | 62 rng_ctr & 0xffff | 63 rng_ctr >> 16 | 64 flags (bit0 right, bit1 left foot contact) |
- *   65:185 terrain_info [20][6] = x,y,z,phi,x_tilt,y_tilt */
+ *   65:185 terrain_info [20][6] = x,y,z,phi,x_tilt,y_tilt | 185 ep_ret_lo (trailing part of the episode return) */
 int ss_get_state(ss_env* env, float* packed, void* stream);
 int ss_set_state(ss_env* env, const float* packed, void* stream);
 /* Observation of the current state without stepping (used after ss_set_state). */
 int ss_get_obs(ss_env* env, float* obs, void* stream);
 
 int32_t ss_num_envs(const ss_env* env);
+/* SS_ABI_VERSION of the library.  A binding must check it at load time (steppingstone_amd/_lib.py does): version 2 inserted
+ * steps_per_launch into ss_rollout_random's argument list, version 3 grew ss_info to 6 words and the packed state to 186. */
 int ss_version(void);
 
 /* Measurement aids (tools/hbm_traffic.py, tools/phase_profile.py); not part of the env protocol.

@@ -35,7 +35,7 @@ typedef SSO_REAL real;
 #define NGRID 11
 #define NCELL 121
 #define OBS_DIM 60
-#define STATE_DIM 185
+#define STATE_DIM 186
 #define RFOOT 8
 #define LFOOT 13
 
@@ -185,7 +185,8 @@ static void chol6_solve(const real L[6][6], const real b[6], real x[6]) {
 /* ------------------------------------------------------------------------------------------------ env state */
 typedef struct {
   real pos[3], quat[4], vel[6], q[NJ], qd[NJ];
-  real pot_prev, z_init, ep_ret, nn_dr;
+  real pot_prev, z_init, nn_dr;
+  double ep_ret;   /* Monitor.update sums the step rewards as Python floats (common/envs_utils.py:131-138) */
   int n, count, elapsed, flags;
   uint32_t rng_ctr;
   real terrain[NSTONE][6];
@@ -195,6 +196,7 @@ typedef struct {
 typedef struct {
   float ep_ret, ep_len;
   int32_t bad_transition, steps_reached, update_terrain;
+  float ep_ret_lo;   /* (double)ep_ret + (double)ep_ret_lo = the fp64 sum of the fp32 step rewards (include/steppingstone.h) */
 } sso_info;
 
 typedef struct {
@@ -802,10 +804,11 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   real energy = ((real)4.5 / NJ) * (e_sum / NJ) + ((real)0.225 / NJ) * (a2 / NJ);
   real r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - (real)0.1 * at_limit;
   if (!finite || !isfinite((double)r)) r = 0;
-  s->ep_ret += r;
+  s->ep_ret += (double)(float)r;
   *rew = (float)r;
   *done = (uint8_t)d;
   info->ep_ret = (float)s->ep_ret;
+  info->ep_ret_lo = (float)(s->ep_ret - (double)info->ep_ret);
   info->ep_len = (float)s->elapsed;
   info->bad_transition = bad;
   info->steps_reached = s->n;
@@ -955,7 +958,8 @@ void sso_get_state(const sso_env* E, real* out) {
     real* o = out + (size_t)e * STATE_DIM;
     memcpy(o, s->pos, 3 * sizeof(real)); memcpy(o + 3, s->quat, 4 * sizeof(real)); memcpy(o + 7, s->vel, 6 * sizeof(real));
     memcpy(o + 13, s->q, NJ * sizeof(real)); memcpy(o + 34, s->qd, NJ * sizeof(real));
-    o[55] = s->pot_prev; o[56] = s->z_init; o[57] = s->ep_ret; o[58] = s->nn_dr;
+    o[55] = s->pot_prev; o[56] = s->z_init; o[57] = (real)(float)s->ep_ret; o[58] = s->nn_dr;
+    o[185] = (real)(float)(s->ep_ret - (double)(float)s->ep_ret);
     o[59] = (real)s->n; o[60] = (real)s->count; o[61] = (real)s->elapsed;
     o[62] = (real)(s->rng_ctr & 0xFFFFu); o[63] = (real)(s->rng_ctr >> 16); o[64] = (real)s->flags;
     memcpy(o + 65, s->terrain, NSTONE * 6 * sizeof(real));
@@ -967,7 +971,7 @@ void sso_set_state(sso_env* E, const real* in) {
     const real* o = in + (size_t)e * STATE_DIM;
     memcpy(s->pos, o, 3 * sizeof(real)); memcpy(s->quat, o + 3, 4 * sizeof(real)); memcpy(s->vel, o + 7, 6 * sizeof(real));
     memcpy(s->q, o + 13, NJ * sizeof(real)); memcpy(s->qd, o + 34, NJ * sizeof(real));
-    s->pot_prev = o[55]; s->z_init = o[56]; s->ep_ret = o[57]; s->nn_dr = o[58];
+    s->pot_prev = o[55]; s->z_init = o[56]; s->ep_ret = (double)o[57] + (double)o[185]; s->nn_dr = o[58];
     s->n = (int)o[59]; s->count = (int)o[60]; s->elapsed = (int)o[61];
     s->rng_ctr = (uint32_t)o[62] | ((uint32_t)o[63] << 16); s->flags = (int)o[64];
     memcpy(s->terrain, o + 65, NSTONE * 6 * sizeof(real));

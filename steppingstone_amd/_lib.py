@@ -8,7 +8,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # STEPPINGSTONE_LIB overrides the path (A/B builds of the same HIP source during tuning); it is still a HIP build.
 LIB_PATH = os.environ.get("STEPPINGSTONE_LIB") or os.path.join(PKG, "lib", "libsteppingstone.so")
 
-OBS_DIM, ACT_DIM, GRID, NCELL, NUM_STONES, STATE_DIM, MAX_EPISODE_STEPS = 60, 21, 11, 121, 20, 185, 1000
+OBS_DIM, ACT_DIM, GRID, NCELL, NUM_STONES, STATE_DIM, MAX_EPISODE_STEPS = 60, 21, 11, 121, 20, 186, 1000
+INFO_WORDS = 6            # ss_info: ep_ret, ep_len, bad_transition, steps_reached, update_terrain, ep_ret_lo
+ABI_VERSION = 3           # include/steppingstone.h SS_ABI_VERSION
 WALKER3D, MIKE = 0, 1
 
 SYMBOLS = [
@@ -75,6 +77,11 @@ def load():
     lib.ss_num_envs.argtypes = [vp]
     lib.ss_num_envs.restype = i32
     lib.ss_version.restype = C.c_int
+    if lib.ss_version() != ABI_VERSION:
+        # the argument lists and struct sizes changed between versions (2: steps_per_launch in ss_rollout_random; 3: ss_info has 6
+        # words, the packed state 186): a stale library would be called with the wrong layout and no error
+        raise SteppingStoneError("%s has ABI version %d, this binding needs %d: rebuild it with `python -m steppingstone_amd.build --force`"
+                                 % (LIB_PATH, lib.ss_version(), ABI_VERSION))
     _lib = lib
     return lib
 

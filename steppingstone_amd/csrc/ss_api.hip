@@ -147,7 +147,7 @@ int launch_rollout(ss_env* env, const ss::StepIO& io, hipStream_t st) {
 extern "C" {
 
 const char* ss_last_error(void) { return g_err.c_str(); }
-int ss_version(void) { return 2; }
+int ss_version(void) { return SS_ABI_VERSION; }
 int32_t ss_num_envs(const ss_env* env) { return env ? env->P.n : 0; }
 
 int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t seed, int64_t env_id_offset) {

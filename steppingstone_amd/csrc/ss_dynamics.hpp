@@ -85,6 +85,14 @@ constexpr int first_child_half(int b) {
 }
 
 #define SS_MEMBAR() asm volatile("" ::: "memory")
+// Between "every lane has written its LDS staging rows" and "the wavefront copies them out together".  On the device a
+// wavefront runs in lockstep and its LDS operations complete in order, so this is a compiler barrier; the host harness runs
+// the 64 lanes as threads and needs a real one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_WAVE_SYNC() asm volatile("" ::: "memory")
+#else
+#define SS_WAVE_SYNC() ss_host_wave_sync()
+#endif
 
 // optional per-phase cycle accounting (-DSS_PROFILE_PHASES; tuning builds only)
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)

@@ -3,7 +3,7 @@
 //
 // HBM layout (structure of arrays, env index fastest so every field access of a wavefront is one coalesced
 // 256-byte transaction):
-//   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8
+//   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8 | ep_ret_lo
 //   istate [NI][Npad] int   : next_step_index, target_reached_count, elapsed, rng_ctr, flags
 //   terrain [20*6][Npad] float : terrain_info (touched only on reset / stone advance / get_state)
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
@@ -17,7 +17,7 @@
 namespace ss {
 
 enum { F_POS = 0, F_QUAT = 3, F_VEL = 7, F_Q = 13, F_QD = 34, F_POT = 55, F_ZINIT = 56, F_EPRET = 57, F_NNDR = 58,
-       F_STONE = 59, NF = 59 + 24 };
+       F_STONE = 59, F_EPRET_LO = 59 + 24, NF = 59 + 24 + 1 };
 enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, NI = 5 };
 constexpr int kNumStones = 20;
 constexpr float kDeg = 0.017453292519943295f;
@@ -338,13 +338,12 @@ struct StepOut {        // what it needs, true world, after the optional reset
 };
 // Observation / info rows are staged in LDS (region A is free at that point) and written out by the whole wavefront as
 // contiguous 256-byte stores: a lane writing its own [60]-float row directly would touch 32 partial cache lines
-// per store instruction (measured 3.1x the algorithmic HBM traffic before this).  The host harness runs lanes one
-// after the other, so it keeps the direct writes.
+// per store instruction (measured 3.1x the algorithmic HBM traffic before this).  One body for the device and for the
+// host pre-flight (tests/host/host_harness.cpp runs the 64 lanes of a wavefront as threads around the same LDS block).
 template <class Model, bool ROLLOUT>
 SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e, int side, bool valid, int lane, int lane_global,
                       int kstep, float* lds) {
   const size_t np = (size_t)P.npad;
-#if defined(__HIP_DEVICE_COMPILE__)
   // Rows are staged back to back in the layout of the output block -- [32][60] for obs, [32][62] = obs | rew | done for the
   // packed block -- so that the wavefront copies the block with float4 loads / stores (8 iterations instead of 31 scalar
   // ones with an index division each; the 4-way bank conflicts of the stride-60 staging writes are fire-and-forget).
@@ -353,12 +352,9 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
   const int stride = packed_layout ? kPackW : SS_OBS_DIM;
   constexpr int kInfoBase = kEnvsPerWave * 64;         // behind the largest staged block
   float* stage = lds + (lane >> 1) * stride;
-  uint32_t* istage = reinterpret_cast<uint32_t*>(lds) + kInfoBase + (lane >> 1) * 5;
+  uint32_t* istage = reinterpret_cast<uint32_t*>(lds) + kInfoBase + (lane >> 1) * SS_INFO_WORDS;
 #define SS_OBS(i) stage[i]
-#else
-  float* op_direct = io.obs + (size_t)e * SS_OBS_DIM;
-#define SS_OBS(i) op_direct[i]
-#endif
+  SS_WAVE_SYNC();          // the staging area is region A: every lane must be through with its contact operators
   if (valid) {
     float* Fo = P.fstate + e;
     // per-joint state + observation entries: own limbs by each lane, spine by the right lane
@@ -403,22 +399,13 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
       for (int i = 0; i < 5; ++i) SS_OBS(55 + i) = t[i];
       if (io.rew) io.rew[e] = o.r;
       if (io.done) io.done[e] = o.d ? 1 : 0;
-#if defined(__HIP_DEVICE_COMPILE__)
       if (packed_layout) {
         stage[SS_OBS_DIM] = o.r;
         stage[SS_OBS_DIM + 1] = o.d ? 1.f : 0.f;
       }
       istage[0] = SS_F2U(o.inf.ep_ret); istage[1] = SS_F2U(o.inf.ep_len);
       istage[2] = (uint32_t)o.inf.bad_transition; istage[3] = (uint32_t)o.inf.steps_reached; istage[4] = (uint32_t)o.inf.update_terrain;
-#else
-      if (io.info) io.info[e] = o.inf;
-      if (io.packed) {
-        float* pk = io.packed + (size_t)e * (SS_OBS_DIM + 2);
-        for (int i = 0; i < SS_OBS_DIM; ++i) pk[i] = op_direct[i];
-        pk[SS_OBS_DIM] = o.r;
-        pk[SS_OBS_DIM + 1] = o.d ? 1.f : 0.f;
-      }
-#endif
+      istage[5] = SS_F2U(o.inf.ep_ret_lo);
 #pragma unroll
       for (int i = 0; i < 3; ++i) Fo[(F_POS + i) * np] = o.pos[i];
 #pragma unroll
@@ -427,11 +414,10 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
       for (int i = 0; i < 3; ++i) { Fo[(F_VEL + i) * np] = o.v0.w[i]; Fo[(F_VEL + 3 + i) * np] = o.v0.v[i]; }
     }
   }
-#if defined(__HIP_DEVICE_COMPILE__)
   {
-    SS_MEMBAR();
+    SS_WAVE_SYNC();
     const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
-    const int nvalid = min(kEnvsPerWave, P.n - env0);
+    const int nvalid = kEnvsPerWave < P.n - env0 ? kEnvsPerWave : P.n - env0;
     // copy the staged block (nfl floats from the start of the LDS staging area) to dst: float4 when dst is 16-byte aligned
     auto copy_block = [&](float* dst, int nfl) {
       if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
@@ -466,8 +452,9 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
     if (io.info) {
       uint32_t* ig = reinterpret_cast<uint32_t*>(io.info + env0);
       const uint32_t* is = reinterpret_cast<const uint32_t*>(lds) + kInfoBase;
-      for (int g = lane; g < nvalid * 5; g += kWave) ig[g] = is[g];
+      for (int g = lane; g < nvalid * SS_INFO_WORDS; g += kWave) ig[g] = is[g];
     }
+#if defined(__HIP_DEVICE_COMPILE__)                   // the peer-store exchange exists on the device only (xGMI stores, system-scope atomics)
     if constexpr (!ROLLOUT) {
       if (io.peers) {
         constexpr int kPack = SS_OBS_DIM + 2;
@@ -487,8 +474,8 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
         }
       }
     }
-  }
 #endif
+  }
 #undef SS_OBS
 }
 
@@ -519,7 +506,11 @@ __device__ __forceinline__ void emit_from_handoff(const Params& P, const StepIO&
   });
   o.r = L.hs(kHandOut + 0);
   o.z_init = L.hs(kHandOut + 1);
-  o.inf.ep_ret = L.hs(kHandOut + 2);
+  {   // the lane pair shares the word: the right lane left the leading part of the episode return, the left lane the trailing part
+    const float w = L.hs(kHandOut + 2), w2 = xchg(w);
+    o.inf.ep_ret = side ? w2 : w;
+    o.inf.ep_ret_lo = side ? w : w2;
+  }
   const int bits = __builtin_bit_cast(int, L.hs(kHandOut2 + 0));
   o.d = bits & 1;
   o.inf.bad_transition = (bits >> 1) & 1;
@@ -671,7 +662,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   load_cache(P, e, c);                          // (keeping these 32 words resident in LDS between the steps of the rollout kernel was
   // measured slower, 0.0556 vs 0.0539 ms/step: the loads' latency is covered by the arithmetic below already)
   float pot_prev = F[F_POT * np], z_init = F[F_ZINIT * np];
-  float ep_ret = F[F_EPRET * np], nn_dr = F[F_NNDR * np];
+  float ep_ret = F[F_EPRET * np], ep_lo = F[F_EPRET_LO * np], nn_dr = F[F_NNDR * np];
   int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
   uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
 
@@ -760,10 +751,18 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   float energy = (4.5f / NJ) * (e_sum / NJ) + (0.225f / NJ) * (a2 / NJ);
   float r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - 0.1f * (float)at_limit;
   if (!finite || !finite_bits(r)) r = 0.f;
-  ep_ret += r;
+  {   // episode return as an unevaluated float pair (ep_ret, ep_lo): error-free two-sum of the step reward, then renormalised, so
+      // that the pair carries the fp64 sum of the fp32 step rewards (Monitor.update sums Python floats, common/envs_utils.py:134)
+    const float s = ep_ret + r, bb = s - ep_ret;
+    const float err = (ep_ret - (s - bb)) + (r - bb);
+    const float lo = ep_lo + err;
+    ep_ret = s + lo;
+    ep_lo = lo - (ep_ret - s);
+  }
   // 10. outputs, auto-reset
   ss_info inf;
   inf.ep_ret = ep_ret;
+  inf.ep_ret_lo = ep_lo;
   inf.ep_len = (float)elapsed;
   inf.bad_transition = bad;
   inf.steps_reached = n;
@@ -796,7 +795,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     z_init = pos[2];
     nn_dr = 0.75f;
     pot_prev = -planar_dist(c.p[1], pos) / kDt;
-    n = 1; count = 0; elapsed = 0; flags = 0; ep_ret = 0.f;
+    n = 1; count = 0; elapsed = 0; flags = 0; ep_ret = 0.f; ep_lo = 0.f;
   }
   // joint values of this lane in the TRUE world (after the optional reset)
   float qt[NH], qdt[NH];
@@ -838,7 +837,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   if constexpr (kOffload) {
     L.hs(kHandOut + 0) = r;
     L.hs(kHandOut + 1) = z_init;
-    L.hs(kHandOut + 2) = inf.ep_ret;
+    L.hs(kHandOut + 2) = side ? inf.ep_ret_lo : inf.ep_ret;
     const int bits = (d ? 1 : 0) | (inf.bad_transition << 1) | (inf.update_terrain << 2) | ((do_reset ? 1 : 0) << 3) | (flags << 4) |
                      (inf.steps_reached << 8) | ((int)inf.ep_len << 16);
     L.hs(kHandOut2 + 0) = __builtin_bit_cast(float, bits);
@@ -870,6 +869,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     Fo[F_POT * np] = pot_prev;
     Fo[F_ZINIT * np] = z_init;
     Fo[F_EPRET * np] = ep_ret;
+    Fo[F_EPRET_LO * np] = ep_lo;
     Fo[F_NNDR * np] = nn_dr;
     P.istate[e + I_N * np] = n;
     P.istate[e + I_COUNT * np] = count;
@@ -997,6 +997,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Params P, float* obs) {
   P.fstate[e + F_POT * np] = pot;
   P.fstate[e + F_ZINIT * np] = z_init;
   P.fstate[e + F_EPRET * np] = 0.f;
+  P.fstate[e + F_EPRET_LO * np] = 0.f;
   P.fstate[e + F_NNDR * np] = nn_dr;
   P.istate[e + I_N * np] = 1;
   P.istate[e + I_COUNT * np] = 0;
@@ -1130,7 +1131,7 @@ __global__ void calib_copy_kernel(const float* __restrict__ in, float* __restric
 }
 #endif
 
-// packed [N,185] <-> structure of arrays (PHYSICS / include/steppingstone.h layout)
+// packed [N,186] <-> structure of arrays (PHYSICS / include/steppingstone.h layout)
 SSD void pack_env(const Params& P, int e, float* packed) {
   const size_t np = (size_t)P.npad;
   float* o = packed + (size_t)e * SS_STATE_DIM;
@@ -1143,6 +1144,7 @@ SSD void pack_env(const Params& P, int e, float* packed) {
   o[63] = (float)(ctr >> 16);
   o[64] = (float)P.istate[e + I_FLAGS * np];
   for (int i = 0; i < 120; ++i) o[65 + i] = P.terrain[e + (size_t)i * np];
+  o[185] = P.fstate[e + (size_t)F_EPRET_LO * np];
 }
 SSD void unpack_env(const Params& P, int e, const float* packed) {
   const size_t np = (size_t)P.npad;
@@ -1155,6 +1157,7 @@ SSD void unpack_env(const Params& P, int e, const float* packed) {
   P.istate[e + I_RNG * np] = (int)((uint32_t)o[62] | ((uint32_t)o[63] << 16));
   P.istate[e + I_FLAGS * np] = (int)o[64];
   for (int i = 0; i < 120; ++i) P.terrain[e + (size_t)i * np] = o[65 + i];
+  P.fstate[e + (size_t)F_EPRET_LO * np] = o[185];
   Cache c;
   cache_from_terrain(P, e, n, c);
   store_cache(P, e, c);

@@ -45,6 +45,7 @@ static __device__ __forceinline__ float ss_rcp(float x) {
 #include <cmath>
 #include <cstring>
 float ss_host_xchg(float x);   // lane-pair exchange, provided by tests/host/host_harness.cpp
+void ss_host_wave_sync();      // barrier over the 64 lane threads of a wavefront (ditto)
 static inline float ss_host_rsqrt(float x) { return 1.0f / sqrtf(x); }
 static inline unsigned ss_host_umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline unsigned ss_host_f2u(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }

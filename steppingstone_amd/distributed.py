@@ -7,8 +7,8 @@ rank * N/G) key the RNG streams, so results do not depend on G.
 
 Two exchange layouts, both written directly by the step kernel (no pack / copy kernels):
   * rollout_random (benchmark, BASELINE configs[3]): the packed [N/G, 62] f32 block obs | rew | done;
-  * step (learner-facing): one flat buffer per rank = packed block + the [N/G, 5] info words (ep_ret, ep_len,
-    bad_transition, steps_reached, update_terrain) behind it, gathered in ONE collective, so the info dict is global
+  * step (learner-facing): one flat buffer per rank = packed block + the [N/G, 6] info words (ep_ret, ep_len,
+    bad_transition, steps_reached, update_terrain, ep_ret_lo) behind it, gathered in ONE collective, so the info dict is global
     like obs / rew / done (what collect() of steppingstone_amd.ppo needs for its masks and episode statistics).
 """
 import os
@@ -19,7 +19,7 @@ import torch.distributed as dist
 from ._lib import ACT_DIM, NCELL, OBS_DIM
 
 PACK = OBS_DIM + 2
-INFO = 5
+INFO = 6            # _lib.INFO_WORDS
 DEPTH = 8
 CHUNK = 32          # control steps per launch / per collective of the chunked rollout exchange
 
@@ -56,6 +56,7 @@ class ShardedVecEnv:
         self._packed = [torch.zeros((self.n_local, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         self._gathered = [torch.zeros((self.num_envs, PACK), dtype=torch.float32, device=dev) for _ in range(DEPTH)]
         self._work = [None] * DEPTH
+        self._last = None           # (kind, buffer index, steps) of the last benchmark exchange, for verify_last_exchange()
         # learner-facing step: packed block and info words in one flat buffer, one collective
         self._chunk = self.n_local * (PACK + INFO)
         self._flat = torch.zeros(self._chunk, dtype=torch.float32, device=dev)
@@ -70,6 +71,52 @@ class ShardedVecEnv:
             from .peer import PeerGather
             self._peer = PeerGather.connect_processes(local_env, group)
             self._info_all = torch.zeros((self.num_envs, INFO), dtype=torch.int32, device=dev)
+        self._peer_steps = 0
+
+    PEER_CHECK_EVERY = 32
+
+    def _check_peer(self, force=False):
+        """The peer-store wait kernel gives up after a bounded spin (about a second) and sets an error word instead of
+        hanging the GPU; rows of a rank that was later than that are then stale.  The consumers must not train on them:
+        the error word is read (one host synchronisation) every PEER_CHECK_EVERY learner-facing steps -- a rollout length,
+        where the training loop synchronises anyway -- and at the end of every benchmark rollout, and a timeout raises.  Rank
+        skew (first-call lazy initialisation, rank-0 checkpoints / evaluation, host stalls) must stay under the timeout, or
+        the exchange must be the default RCCL all-gather."""
+        if self._peer is None:
+            return
+        self._peer_steps += 1
+        if force or self._peer_steps % self.PEER_CHECK_EVERY == 0:
+            n = self._peer.error()
+            if n:
+                raise RuntimeError("peer-store all-gather: %d wait(s) timed out -- a rank was more than the spin bound late, the "
+                                   "gathered rows of that step are stale; use the RCCL exchange (peer_gather=False) or remove the "
+                                   "rank skew" % n)
+
+    # -- self-proof of the exchange
+    def verify_last_exchange(self):
+        """Collective.  Checks that the buffers of the LAST benchmark exchange (rollout_random / rollout_random_chunked with
+        gather) really hold every rank's block: each rank checksums (exact int64 sum of the bit patterns) its own packed block
+        and the block of every peer as it received it; the own checksums are all-gathered and compared with the received
+        ones on every rank; the verdict is all-reduced (MIN).  Returns (verified, ranks)."""
+        if not self._collective or self._last is None:
+            return None, self.world
+        kind, idx, ns = self._last
+        if kind == "chunk":
+            own = self._chunk_local[idx][:ns]
+            got = self._chunk_all[idx].view(self.world, -1, self.n_local, PACK)[:, :ns]
+        else:
+            own = self._packed[idx]
+            got = self._gathered[idx].view(self.world, self.n_local, PACK)
+        cs = lambda x: x.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)          # noqa: E731
+        mine = cs(own)
+        seen = torch.cat([cs(got[r]) for r in range(self.world)])
+        alls = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(alls, mine, group=self.group)
+        ok = (seen == alls).all().to(torch.int32).reshape(1)
+        # a rank whose own block is all zeros (nothing was stepped) proves nothing
+        ok = ok * (own.abs().sum() > 0).to(torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(ok.item()), self.world
 
     # -- helpers
     def local_slice(self):
@@ -93,7 +140,7 @@ class ShardedVecEnv:
         return self._gathered[slot]
 
     def _gather_flat(self):
-        """One collective for packed block + info words; returns global (packed [N,62], info [N,5] int32)."""
+        """One collective for packed block + info words; returns global (packed [N,62], info [N,6] int32)."""
         if not self._collective:
             return self._flat_packed, self._flat_info
         dist.all_gather_into_tensor(self._flat_all, self._flat, group=self.group)
@@ -104,9 +151,9 @@ class ShardedVecEnv:
 
     @staticmethod
     def _info_dict(info):
-        fl = info[:, 0:2].view(torch.float32)
+        fl = info.view(torch.float32)
         return {"ep_ret": fl[:, 0], "ep_len": fl[:, 1], "bad_transition": info[:, 2], "steps_reached": info[:, 3],
-                "update_terrain": info[:, 4]}
+                "update_terrain": info[:, 4], "ep_ret_lo": fl[:, 5]}
 
     # -- VecEnv protocol on GLOBAL arrays
     def reset(self):
@@ -128,6 +175,7 @@ class ShardedVecEnv:
             slot = self._peer.step(actions=a, info=self._flat_info)
             dist.all_gather_into_tensor(self._info_all, self._flat_info, group=self.group)
             gobs, grew, gdone = self._split(self._peer.wait(slot))
+            self._check_peer()
             return gobs, grew, gdone, self._info_dict(self._info_all)
         self.local.step_packed(self._flat_packed, actions=a, info=self._flat_info)
         packed, info = self._gather_flat()
@@ -165,6 +213,7 @@ class ShardedVecEnv:
                 self._chunk_work[b].wait()
                 self._chunk_work[b] = None
         b, ns = last
+        self._last = ("chunk", b, ns) if (gather and self._collective) else None
         if gather and self._collective:
             g = self._chunk_all[b].view(self.world, chunk, self.n_local, PACK)[:, ns - 1].reshape(self.num_envs, PACK)
         else:
@@ -180,6 +229,7 @@ class ShardedVecEnv:
             g = None
             for k in range(num_steps):
                 g = self._peer.wait(self._peer.step(actions=None, t=t0 + k))
+            self._check_peer(force=True)
             return self._split(g)
         slot = 0
         for k in range(num_steps):
@@ -192,6 +242,7 @@ class ShardedVecEnv:
                 self._gather_packed(slot, async_op=True)
         for i in range(DEPTH):
             self._wait(i)
+        self._last = ("step", slot, 1) if (gather and self._collective and num_steps > 0) else None
         g = self._gathered[slot] if (gather and self._collective) else self._packed[slot]
         return self._split(g)
 

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_DIM, GRID, MAX_EPISODE_STEPS, NCELL, NUM_STONES, OBS_DIM, STATE_DIM, SteppingStoneError
+from ._lib import ACT_DIM, GRID, INFO_WORDS, MAX_EPISODE_STEPS, NCELL, NUM_STONES, OBS_DIM, STATE_DIM, SteppingStoneError
 
 DEG = np.pi / 180.0
 ENV_KINDS = {
@@ -181,7 +181,7 @@ class SteppingStoneVecEnv:
         self._obs = torch.zeros((n, OBS_DIM), dtype=torch.float32, device=dev)
         self._rew = torch.zeros((n,), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
-        self._info = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+        self._info = torch.zeros((n, INFO_WORDS), dtype=torch.int32, device=dev)
         self._act = torch.zeros((n, ACT_DIM), dtype=torch.float32, device=dev)
         self._pending = False
         # numpy drop-in mode on a GPU: pinned staging buffers, one H->D copy of the actions and one D->H copy of the
@@ -366,7 +366,7 @@ class SteppingStoneVecEnv:
     @property
     def terrain_info(self):
         """(N,20,6) x,y,z,phi,x_tilt,y_tilt (playground/enjoy.py:60-64)."""
-        return self.get_state()[:, 65:].reshape(self.num_envs, NUM_STONES, 6).cpu().numpy()
+        return self.get_state()[:, 65:185].reshape(self.num_envs, NUM_STONES, 6).cpu().numpy()
 
     @property
     def next_step_index(self):
@@ -377,9 +377,9 @@ class SteppingStoneVecEnv:
         return self._obs.cpu().numpy() if self.return_numpy else self._obs
 
     def _info_tensors(self):
-        fl = self._info[:, 0:2].view(torch.float32)
+        fl = self._info.view(torch.float32)
         return {"ep_ret": fl[:, 0], "ep_len": fl[:, 1], "bad_transition": self._info[:, 2],
-                "steps_reached": self._info[:, 3], "update_terrain": self._info[:, 4]}
+                "steps_reached": self._info[:, 3], "update_terrain": self._info[:, 4], "ep_ret_lo": fl[:, 5]}
 
     def _info_dicts(self, done):
         """Sequence of N info dicts with the reference's keys (common/envs_utils.py:59-65,131-153)."""
@@ -387,10 +387,12 @@ class SteppingStoneVecEnv:
         idx = np.nonzero(done)[0]
         if idx.size:
             raw = self._info.cpu().numpy()
-            fl = raw[:, 0:2].view(np.float32)
+            fl = raw.view(np.float32)
             now = round(time.time() - self._tstart, 6)
             for i in idx:
-                d = {"episode": {"r": round(float(fl[i, 0]), 6), "l": int(fl[i, 1]), "t": now},
+                # Monitor.update: eprew = sum(self.rewards) in Python floats, "r": round(eprew, 6) (common/envs_utils.py:134-138);
+                # the kernel's (ep_ret, ep_ret_lo) pair is that fp64 sum of the fp32 step rewards
+                d = {"episode": {"r": round(float(fl[i, 0]) + float(fl[i, 5]), 6), "l": int(fl[i, 1]), "t": now},
                      "steps_reached": int(raw[i, 3])}
                 if raw[i, 2]:
                     d["bad_transition"] = True

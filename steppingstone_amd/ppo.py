@@ -270,6 +270,21 @@ class EpisodeRing:
         b = self.buf[:self.size].cpu()
         return b if c == self.size else b[:c]       # before the first wrap the filled slots are 0..count-1
 
+    def all_ranks_values(self):
+        """Host copy of the stored returns of EVERY rank's ring (collective under torch.distributed): what the CSV row of a
+        multi-rank run reports, so that it is the same statistic that gates the curriculum."""
+        if _dist_world() <= 1:
+            return self.values()
+        import torch.distributed as dist
+        w = _dist_world()
+        bufs = torch.zeros((w, self.size), device=self.buf.device, dtype=self.buf.dtype)
+        cnts = torch.zeros(w, dtype=torch.long, device=self.buf.device)
+        dist.all_gather_into_tensor(bufs, self.buf[:self.size].contiguous())
+        dist.all_gather_into_tensor(cnts, self.count.reshape(1))
+        bufs, cnts = bufs.cpu(), cnts.cpu().tolist()
+        parts = [bufs[r] if c == self.size else bufs[r, :c] for r, c in enumerate(cnts) if c]
+        return torch.cat(parts) if parts else torch.empty(0)
+
     def all_ranks_sum_count(self):
         """(sum, count) over every rank's ring: the curriculum gate must be one decision for all ranks."""
         v = torch.stack([self.buf[:self.size].sum().double(), self.count.double()])
@@ -431,7 +446,7 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
           gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto",
           sampling="none", eval_envs=None, curriculum_threshold=0.85, uniform_every=500000,
           test_envs=None, test_interval=1, logger=None, save_dir="", save_every=1e7, env_name="env",
-          use_specialist=False, learner="auto"):
+          use_specialist=False, learner="torch"):
     """The training loop of playground/train.py:211-578 on device tensors.  Returns (actor_critic, per-update stats).
 
       use_curriculum   fixed-order curriculum: level += 1 while mean(recent episode returns) > 1000 (train.py:115-118,503-506)
@@ -445,10 +460,11 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
       logger           ConsoleCSVLogger-compatible object (steppingstone_amd.csv_logger): log_epoch(dict) per update
       save_dir         `{env}_latest.pt` every update, `{env}_{frames}.pt` every save_every frames, `{env}_best.pt` on a new
                        best mean return (train.py:523-562)
-      learner          "fused": the minibatch step runs in the hand-written MFMA kernels of steppingstone_amd.fused_ppo (GPU,
-                       minibatch a multiple of 32 that divides the rank's rollout; with several ranks one all-reduce of
-                       the flat gradient sits between its gradient and Adam halves); "torch": autograd +
-                       torch.optim.Adam (steppingstone_amd.ppo.PPO); "auto": fused whenever its conditions hold
+      learner          "torch" (default; BASELINE configs[4]: "actor/critic on PyTorch-ROCm"): autograd + torch.optim.Adam
+                       (steppingstone_amd.ppo.PPO); "fused" (opt-in): the minibatch step runs in the hand-written MFMA kernels
+                       of steppingstone_amd.fused_ppo (GPU, minibatch a multiple of 32 that divides the rank's rollout; with
+                       several ranks one all-reduce of the flat gradient sits between its gradient and Adam halves);
+                       "auto": fused when its conditions hold AND its library loads, else torch with a one-line warning
     use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs.  Episode returns go
     through a device ring of the last num_envs episodes in both modes (EpisodeRing = the reference's deque).
     Under torch.distributed (one rank per GPU) every rank passes its LOCAL envs: gradients and the advantage statistics
@@ -473,11 +489,19 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
     fused_ok = dev.type == "cuda" and mini_batch_size % 32 == 0 and (num_steps * n) % mini_batch_size == 0
     if learner == "fused" and not fused_ok:
         raise ValueError("learner='fused' needs a GPU and a minibatch (multiple of 32) dividing the rank's rollout")
+    if learner not in ("torch", "fused", "auto"):
+        raise ValueError("learner must be 'torch', 'fused' or 'auto', got %r" % (learner,))
+    agent = None
     if learner == "fused" or (learner == "auto" and fused_ok):
-        from .fused_ppo import FusedPPO
-        agent = FusedPPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror,
-                         use_graph=bool(use_graph))
-    else:
+        from .fused_ppo import FusedLearnerError, FusedPPO
+        try:
+            agent = FusedPPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror,
+                             use_graph=bool(use_graph))
+        except FusedLearnerError as exc:
+            if learner == "fused":                         # asked for explicitly: fail loudly
+                raise
+            print("steppingstone_amd.ppo.train: fused learner unavailable (%s); using the torch learner" % exc)
+    if agent is None:
         agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=use_graph)
     roll = Rollouts(num_steps, n, dev)
     ring = EpisodeRing(n, dev)
@@ -567,8 +591,8 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
                  "value_loss": vl, "action_loss": al, "mean_rew": mean_ret, "curriculum": curriculum,
                  "grid_updated": grid_updated}
         history.append(stats)
-        if logger is not None and rank == 0 and cnt > 1:      # train.py:564: only once episodes have finished
-            vals = ring.values()
+        vals = ring.all_ranks_values() if (logger is not None and cnt > 1) else None     # collective: every rank calls it
+        if logger is not None and rank == 0 and cnt > 1 and vals.numel():      # train.py:564: only once episodes have finished
             logger.log_epoch({"iter": j + 1, "total_num_steps": frames, "fps": stats["fps"], "entropy": ent,
                               "value_loss": vl, "action_loss": al, "stats": {"rew": vals.numpy()},
                               "test_stats": {"rew": (test_rets if test_rets.numel() else torch.full((1,), float("nan"))).numpy()}})

@@ -12,15 +12,18 @@
 
 #include "../../steppingstone_amd/csrc/ss_kernels.hpp"
 
-// ---- lane-pair exchange on the host: the two lanes of an env run as two threads that meet at every exchange
+// ---- a wavefront on the host: its 64 lanes run as 64 threads around one LDS block.  The two lanes of an env meet at
+// every lane-pair exchange; all 64 meet where the device code relies on the wavefront's lockstep (SS_WAVE_SYNC: between
+// the staging of the output rows and their block copy in emit_outputs).
 namespace {
-struct PairSync {
+struct Barrier {
+  const int parties;
   std::atomic<int> arrived{0};
   std::atomic<int> generation{0};
-  float slot[2];
-  void barrier() {
+  explicit Barrier(int n) : parties(n) {}
+  void wait() {
     int g = generation.load(std::memory_order_acquire);
-    if (arrived.fetch_add(1, std::memory_order_acq_rel) == 1) {
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) == parties - 1) {
       arrived.store(0, std::memory_order_relaxed);
       generation.store(g + 1, std::memory_order_release);
     } else {
@@ -28,18 +31,24 @@ struct PairSync {
     }
   }
 };
+struct PairSync {
+  Barrier b{2};
+  float slot[2];
+};
 thread_local PairSync* t_sync = nullptr;
+thread_local Barrier* t_wave = nullptr;
 thread_local int t_side = 0;
 }  // namespace
 
 float ss_host_xchg(float x) {
   PairSync* s = t_sync;
   s->slot[t_side] = x;
-  s->barrier();
+  s->b.wait();
   float r = s->slot[1 - t_side];
-  s->barrier();
+  s->b.wait();
   return r;
 }
+void ss_host_wave_sync() { t_wave->wait(); }
 
 namespace {
 void window_prob(float* p, int c) {
@@ -56,7 +65,7 @@ void window_prob(float* p, int c) {
 
 extern "C" {
 
-// one control step of n envs: packed state in/out [n,185], act [n,21]; outputs obs [n,60], rew, done, info
+// one control step of n envs: packed state in/out [n,186], act [n,21]; outputs obs [n,60], rew, done, info
 int hh_step(int kind, int n, unsigned long long seed, int curriculum, const double* prob /*121 or null*/,
             const float* packed_in, const float* act, float* packed_out, float* obs, float* rew,
             unsigned char* done, ss_info* info) {
@@ -72,21 +81,25 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   K.prob = pr.data(); K.per_env_prob = 0; K.curriculum = curriculum; K.power = 1.f; K.auto_reset = 1;
   P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.knobs = &K;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
-  std::vector<float4> lds((size_t)ss::kLdsSlots * 64);
   ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0, 0};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
-  for (int e = 0; e < n; ++e) {
-    PairSync sync;
-    auto run = [&](int side) {
-      t_sync = &sync;
-      t_side = side;
-      const int lg = 2 * e + side;
-      if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, lg, lg % 64, reinterpret_cast<float*>(lds.data()));
-      else ss::step_env<ss::ModelMike, false>(P, io, lg, lg % 64, reinterpret_cast<float*>(lds.data()));
+  const int waves = (2 * n + 63) / 64;
+  for (int w = 0; w < waves; ++w) {                      // one wavefront = 32 envs = 64 lane threads, as on the device
+    std::vector<float4> lds((size_t)ss::kLdsSlots * 64);
+    Barrier wave(64);
+    std::vector<PairSync> pairs(32);
+    auto run = [&](int lane) {
+      t_sync = &pairs[lane >> 1];
+      t_wave = &wave;
+      t_side = lane & 1;
+      const int lg = 64 * w + lane;                      // lanes past the last env redo it with valid = false, like the device
+      if (kind == 0) ss::step_env<ss::ModelWalker3D, false>(P, io, lg, lane, reinterpret_cast<float*>(lds.data()));
+      else ss::step_env<ss::ModelMike, false>(P, io, lg, lane, reinterpret_cast<float*>(lds.data()));
     };
-    std::thread other(run, 1);
+    std::vector<std::thread> th;
+    for (int lane = 1; lane < 64; ++lane) th.emplace_back(run, lane);
     run(0);
-    other.join();
+    for (auto& t : th) t.join();
   }
   for (int e = 0; e < n; ++e) ss::pack_env(P, e, packed_out);
   return 0;

@@ -13,7 +13,7 @@ SRC = os.path.join(HOST_DIR, "host_harness.cpp")
 CSRC = os.path.join(ROOT, "steppingstone_amd", "csrc")
 
 INFO_DTYPE = np.dtype([("ep_ret", "f4"), ("ep_len", "f4"), ("bad_transition", "i4"), ("steps_reached", "i4"),
-                       ("update_terrain", "i4")])
+                       ("update_terrain", "i4"), ("ep_ret_lo", "f4")])
 
 
 def build():

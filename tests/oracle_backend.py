@@ -24,9 +24,10 @@ class OracleBackend:
         obs.copy_(torch.from_numpy(o))
         rew.copy_(torch.from_numpy(r))
         done.copy_(torch.from_numpy(d))
-        raw = np.zeros((self.n, 5), np.int32)
-        raw[:, 0:2].view(np.float32)[:, 0] = i["ep_ret"]
-        raw[:, 0:2].view(np.float32)[:, 1] = i["ep_len"]
+        raw = np.zeros((self.n, 6), np.int32)
+        raw.view(np.float32)[:, 0] = i["ep_ret"]
+        raw.view(np.float32)[:, 1] = i["ep_len"]
+        raw.view(np.float32)[:, 5] = i["ep_ret_lo"]
         raw[:, 2], raw[:, 3], raw[:, 4] = i["bad_transition"], i["steps_reached"], i["update_terrain"]
         info.copy_(torch.from_numpy(raw))
 

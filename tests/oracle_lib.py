@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-OBS_DIM, ACT_DIM, STATE_DIM, NCELL = 60, 21, 185, 121
+OBS_DIM, ACT_DIM, STATE_DIM, NCELL = 60, 21, 186, 121
 KIND = {"walker3d": 0, "mike": 1}
 
 
@@ -24,11 +24,11 @@ def tap_dtype(real):
 
 class Info(C.Structure):
     _fields_ = [("ep_ret", C.c_float), ("ep_len", C.c_float), ("bad_transition", C.c_int32),
-                ("steps_reached", C.c_int32), ("update_terrain", C.c_int32)]
+                ("steps_reached", C.c_int32), ("update_terrain", C.c_int32), ("ep_ret_lo", C.c_float)]
 
 
 INFO_DTYPE = np.dtype([("ep_ret", "f4"), ("ep_len", "f4"), ("bad_transition", "i4"), ("steps_reached", "i4"),
-                       ("update_terrain", "i4")])
+                       ("update_terrain", "i4"), ("ep_ret_lo", "f4")])
 
 
 def build():
@@ -48,7 +48,9 @@ def load(prec="f32"):
     if prec in _libs:
         return _libs[prec]
     build()
-    lib = C.CDLL(os.path.join(ORACLE_DIR, "lib", "libss_oracle_%s.so" % prec))
+    # SS_ORACLE_LIB_F32 / _F64: another build of the same source (bench.py's cpu_baseline leg points its worker processes
+    # at the -O3 -march=native build it made on the box)
+    lib = C.CDLL(os.environ.get("SS_ORACLE_LIB_%s" % prec.upper()) or os.path.join(ORACLE_DIR, "lib", "libss_oracle_%s.so" % prec))
     vp, i32, u64, i64, dbl = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_double
     lib.sso_create.restype = vp
     lib.sso_create.argtypes = [i32, i32, u64, i64]
@@ -273,3 +275,4 @@ def debug_fk(kind, packed, prec="f64"):
 S_POS, S_QUAT, S_VEL, S_Q, S_QD = slice(0, 3), slice(3, 7), slice(7, 13), slice(13, 34), slice(34, 55)
 S_POT, S_ZINIT, S_EPRET, S_NNDR, S_N, S_COUNT, S_ELAPSED, S_CTRLO, S_CTRHI, S_FLAGS = range(55, 65)
 S_TERRAIN = slice(65, 185)
+S_EPRET_LO = 185

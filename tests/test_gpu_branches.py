@@ -131,7 +131,7 @@ def test_per_env_grids_at_full_size():
             same = (sg[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1)
             assert (same | (mg[:, 0] < 1e-5)).all(), (path, np.nonzero(~same)[0][:8], mg[~same, 0][:8])
             flips += int((~same).sum())
-            assert np.abs(sg[same, 65:] - so[same, 65:]).max() < 1e-5, path
+            assert np.abs(sg[same, 65:185] - so[same, 65:185]).max() < 1e-5, path
             drawn |= io["update_terrain"].astype(bool)
             g.set_state(so)
         assert flips <= 8, flips
@@ -160,7 +160,7 @@ def _mirror_state(st, idx):
         m[:, base:base + 21] = out
     fl = st[:, 64].astype(np.int64)
     m[:, 64] = ((fl & 1) << 1) | ((fl >> 1) & 1)    # foot contact bits swap
-    terr = m[:, 65:].reshape(-1, 20, 6)
+    terr = m[:, 65:185].reshape(-1, 20, 6)
     terr[:, :, 1] *= -1                             # y
     terr[:, :, 3] *= -1                             # phi (rotation about z)
     terr[:, :, 4] *= -1                             # x_tilt (rotation about x); y_tilt is unchanged
@@ -330,7 +330,7 @@ def test_hooks_reach_a_captured_graph():
         sg, se = g_env.get_state(), e_env.get_state()
         assert torch.equal(sg, se), name
         assert torch.equal(g_env._obs, e_env._obs) and torch.equal(g_env._rew, e_env._rew), name
-        terr = sg[:, 65:].reshape(n, 20, 6)
+        terr = sg[:, 65:185].reshape(n, 20, 6)
         drawn = sg[:, 59] >= 2
         assert drawn.float().mean() > 0.5, name
         tilt, yaw = terr[drawn, 3, 4].abs().max().item(), terr[drawn, 3, 3].abs().max().item()   # stone 3 = first drawn stone
@@ -399,3 +399,49 @@ def test_closed_loop_1000_step_drift(env_id, kind):
     for lo, hi in ((0, 100), (100, 300), (300, 999)):                               # (ii)
         assert np.median(med_g[lo:hi]) < 5 * np.median(med_3[lo:hi]) + 1e-6, (lo, hi, np.median(med_g[lo:hi]), np.median(med_3[lo:hi]))
     g.close()
+
+
+def test_episode_return_is_the_fp64_sum_of_the_step_rewards():
+    """Monitor.update sums the step rewards as Python floats and reports round(sum, 6) (common/envs_utils.py:131-138).  The
+    kernel carries the running sum as a float pair (two-sum per step): float64(ep_ret) + float64(ep_ret_lo) at the end of
+    an episode must be the fp64 sum of the fp32 rewards the env returned, and info["episode"]["r"] its 6-decimal rounding --
+    for episodes up to the 1000-step limit (a plain fp32 accumulator is off by ~1e-4 relative there)."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    n = 256
+    g = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=3, device="cuda:0", return_numpy=False)
+    g.reset()
+    acc = np.zeros(n, np.float64)
+    checked, longest, worst32 = 0, 0, 0.0
+    ctrl = balance_controller("walker3d")       # half the robots stand for the full 1000-step episode, the others act randomly
+    obs = g._obs
+    for t in range(1100):
+        act = g.random_actions(t)
+        act[:n // 2] = torch.as_tensor(ctrl(obs[:n // 2].cpu().numpy()), device="cuda:0")
+        obs, rew, done, info = g.step(act)
+        acc += rew.cpu().numpy().astype(np.float64)
+        d = done.cpu().numpy()
+        if d.any():
+            hi, lo = info["ep_ret"].cpu().numpy().astype(np.float64), info["ep_ret_lo"].cpu().numpy().astype(np.float64)
+            ln = info["ep_len"].cpu().numpy()
+            assert np.abs((hi + lo)[d] - acc[d]).max() < 1e-9 * max(1.0, np.abs(acc[d]).max())
+            assert (np.abs(lo[d]) <= np.spacing(np.abs(hi[d]).astype(np.float32)).astype(np.float64)).all()
+            worst32 = max(worst32, float(np.abs(hi[d] - acc[d]).max()))
+            longest = max(longest, int(ln[d].max()))
+            checked += int(d.sum())
+            acc[d] = 0.0
+    assert checked > n and longest == 1000
+    print("episode returns: %d episodes checked, longest %d steps; the leading float alone is off by up to %.1e" % (checked, longest, worst32))
+    # the numpy (reference-style) mode reports round(hi + lo, 6)
+    e = SteppingStoneVecEnv("Walker3DStepperEnv-v0", 64, seed=3, device="cuda:0", return_numpy=True)
+    e.reset()
+    acc = np.zeros(64)
+    seen = 0
+    for t in range(150):
+        o, r, d, infos = e.step(e.random_actions(t).cpu().numpy())
+        acc += r
+        for i in np.nonzero(d)[0]:
+            assert infos[i]["episode"]["r"] == round(acc[i], 6)
+            acc[i] = 0.0
+            seen += 1
+    assert seen > 64
+    g.close(); e.close()

@@ -166,7 +166,7 @@ def test_target_advance_and_sampler_are_bit_exact(env_id, kind):
         assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS])
         # the drawn stone (terrain rows) must agree to rounding; the sampled cell is discrete, so a wrong cell
         # would show up as a >= 4 degree / 6 degree jump
-        assert np.abs(sg[:, 65:] - so[:, 65:]).max() < 1e-5
+        assert np.abs(sg[:, 65:185] - so[:, 65:185]).max() < 1e-5
         g.set_state(so)
     assert advanced.mean() > 0.5     # a torque-free robot keeps a foot on the stone for 2 steps in most envs
     # step bonus was paid on first touch: reward parity covers it
@@ -333,7 +333,7 @@ def test_episode_statistics_match_oracle():
         a = o.random_actions(t)
         _, _, dg, _ = g.step(a)
         raw = g._info.cpu().numpy()
-        fl = raw[:, 0:2].view(np.float32)
+        fl = raw.view(np.float32)
         lg += list(fl[dg, 1]); rg_ += list(fl[dg, 0])
         _, _, do, io = o.step(a)
         m = do.astype(bool)
@@ -557,7 +557,7 @@ def test_remaining_hooks_match_oracle():
     for t in range(3):
         o.step(zero); g.step(zero)
         sg, so = g.get_state().cpu().numpy(), o.get_state()
-        assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS]) and np.abs(sg[:, 65:] - so[:, 65:]).max() < 1e-5
+        assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS]) and np.abs(sg[:, 65:185] - so[:, 65:185]).max() < 1e-5
         g.set_state(so)
     # auto-reset off: a finished env reports done and keeps its terminal observation until reset() is called
     g.backend.set_auto_reset(False); o.set_auto_reset(0)

@@ -81,9 +81,11 @@ class ScriptedBackend:
         self.t += 1
         self.ret += r
         d = self.t >= 4 + np.arange(self.n)
-        raw = np.zeros((self.n, 5), np.int32)
-        raw[:, 0:2].view(np.float32)[:, 0] = self.ret
-        raw[:, 0:2].view(np.float32)[:, 1] = self.t
+        raw = np.zeros((self.n, 6), np.int32)
+        hi = self.ret.astype(np.float32)
+        raw.view(np.float32)[:, 0] = hi
+        raw.view(np.float32)[:, 1] = self.t
+        raw.view(np.float32)[:, 5] = (self.ret - hi.astype(np.float64)).astype(np.float32)
         info.copy_(torch.from_numpy(raw))
         rew.copy_(torch.from_numpy(r.astype(np.float32)))
         done.copy_(torch.from_numpy(d.astype(np.uint8)))
@@ -109,7 +111,7 @@ def test_vecenv_protocol_matches_reference_shmemvecenv():
         assert np.array_equal(d, G["vec_done"][t])
         for i in range(n):
             if d[i]:
-                assert abs(infos[i]["episode"]["r"] - G["vec_ep_r"][t, i]) < 1e-5
+                assert infos[i]["episode"]["r"] == G["vec_ep_r"][t, i]      # fp64 sum of the step rewards, round(., 6): Monitor.update
                 assert infos[i]["episode"]["l"] == G["vec_ep_l"][t, i]
                 assert "t" in infos[i]["episode"]
             else:

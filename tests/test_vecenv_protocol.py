@@ -39,7 +39,7 @@ def test_tensor_mode_and_hooks():
     obs = env.reset()
     assert torch.is_tensor(obs) and obs.shape == (5, 60)
     obs, rew, done, info = env.step(torch.zeros(5, 21))
-    assert done.dtype == torch.bool and set(info) == {"ep_ret", "ep_len", "bad_transition", "steps_reached", "update_terrain"}
+    assert done.dtype == torch.bool and set(info) == {"ep_ret", "ep_len", "bad_transition", "steps_reached", "update_terrain", "ep_ret_lo"}
     env.update_curriculum(3)
     env.update_specialist(2)
     env.update_sample_prob(np.full((5, 11, 11), 1 / 121.0))
