@@ -234,6 +234,19 @@ SSD SV imp_down(const JointCache& jc, const float* ul, const SV& dpar, float* dq
   return d;
 }
 
+SSD JRec opaque_rec(const JRec& r) {
+  // through local scalars, field by field: with the asm operands inside a struct copy one record of the helpers' part A stayed in
+  // scratch (32 B per lane stored and re-loaded every substep, and written back at the end of every launch: 0.8 MB of the 4096-env
+  // step's HBM traffic, the "1.65 x" of round 2's five-barrier schedule)
+  float cs = r.cs, sn = r.sn, Dinv = r.Dinv, u = r.u;
+  float w0 = r.Uw[0], w1 = r.Uw[1], w2 = r.Uw[2], v0 = r.Uv[0], v1 = r.Uv[1], v2 = r.Uv[2];
+  SS_REG(cs); SS_REG(sn); SS_REG(Dinv); SS_REG(u);
+  SS_REG(w0); SS_REG(w1); SS_REG(w2); SS_REG(v0); SS_REG(v1); SS_REG(v2);
+  JRec o;
+  o.cs = cs; o.sn = sn; o.Dinv = Dinv; o.u = u;
+  o.Uw[0] = w0; o.Uw[1] = w1; o.Uw[2] = w2; o.Uv[0] = v0; o.Uv[1] = v1; o.Uv[2] = v2;
+  return o;
+}
 // two columns at once in packed f32: the unloaded down step applies the same joint operator to every column of T, so
 // a pair of columns shares each instruction (v_pk_*), coefficients broadcast
 template <class Model, int J>
@@ -241,7 +254,8 @@ SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
   constexpr int ax = kAxis[J], k = half_pos(J), ai = (ax + 1) % 3, aj = (ax + 2) % 3;
   constexpr float rx = Model::r[J][0], ry = Model::r[J][1], rz = Model::r[J][2];
   const JRec& r = jc.r[k];
-  const float c = r.cs, s = r.sn;
+  float c = r.cs, s = r.sn;
+  SS_REG(c); SS_REG(s);
   SV2 d;
   d.w[ax] = p.w[ax];
   d.w[ai] = p.w[ai] * c + p.w[aj] * s;
@@ -258,8 +272,13 @@ SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
   d.v[ax] = t[ax];
   d.v[ai] = t[ai] * c + t[aj] * s;
   d.v[aj] = t[aj] * c - t[ai] * s;
-  ssf2 dotv = d.w[0] * r.Uw[0] + d.w[1] * r.Uw[1] + d.w[2] * r.Uw[2] + d.v[0] * r.Uv[0] + d.v[1] * r.Uv[1] + d.v[2] * r.Uv[2];
-  d.w[ax] -= dotv * r.Dinv;
+  // the record's fields as opaque register values: a splat of a field that is still a load when instcombine runs becomes an
+  // overlapping <2 x float> load, and the record then stays in scratch (the ankle record did: 32 B per helper lane stored and
+  // re-loaded every substep and written back at the end of every launch)
+  float uw0 = r.Uw[0], uw1 = r.Uw[1], uw2 = r.Uw[2], uv0 = r.Uv[0], uv1 = r.Uv[1], uv2 = r.Uv[2], di = r.Dinv;
+  SS_REG(uw0); SS_REG(uw1); SS_REG(uw2); SS_REG(uv0); SS_REG(uv1); SS_REG(uv2); SS_REG(di);
+  ssf2 dotv = d.w[0] * uw0 + d.w[1] * uw1 + d.w[2] * uw2 + d.v[0] * uv0 + d.v[1] * uv1 + d.v[2] * uv2;
+  d.w[ax] -= dotv * di;
   return d;
 }
 
@@ -268,13 +287,17 @@ SSD SV2 imp_up_pair(const JointCache& jc, ssf2* ul2, const SV2& p) {
   constexpr int ax = kAxis[J], k = half_pos(J), ai = (ax + 1) % 3, aj = (ax + 2) % 3;
   constexpr float rx = Model::r[J][0], ry = Model::r[J][1], rz = Model::r[J][2];
   const JRec& r = jc.r[k];
-  const float c = r.cs, s = r.sn;
+  float c = r.cs, s = r.sn, di = r.Dinv;
+  float uw[3] = {r.Uw[0], r.Uw[1], r.Uw[2]}, uv[3] = {r.Uv[0], r.Uv[1], r.Uv[2]};
+  SS_REG(c); SS_REG(s); SS_REG(di);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { SS_REG(uw[i]); SS_REG(uv[i]); }
   const ssf2 u = -p.w[ax];
   ul2[k] = u;
-  const ssf2 du = u * r.Dinv;
+  const ssf2 du = u * di;
   ssf2 fw[3], fv[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { fw[i] = p.w[i] + du * r.Uw[i]; fv[i] = p.v[i] + du * r.Uv[i]; }
+  for (int i = 0; i < 3; ++i) { fw[i] = p.w[i] + du * uw[i]; fv[i] = p.v[i] + du * uv[i]; }
   SV2 o;                                             // f_p = R f_c,  n_p = R n_c + r x f_p
   o.v[ax] = fv[ax]; o.v[ai] = fv[ai] * c - fv[aj] * s; o.v[aj] = fv[ai] * s + fv[aj] * c;
   o.w[ax] = fw[ax]; o.w[ai] = fw[ai] * c - fw[aj] * s; o.w[aj] = fw[ai] * s + fw[aj] * c;
@@ -293,7 +316,9 @@ SSD SV2 imp_down_pair_loaded(const JointCache& jc, const ssf2* ul2, const SV2& p
   constexpr int ax = kAxis[J], k = half_pos(J);
   const JRec& r = jc.r[k];
   SV2 d = imp_down_pair<Model, J>(jc, p);            // includes  - Dinv * (U . d)
-  d.w[ax] += ul2[k] * r.Dinv;
+  float di = r.Dinv;
+  SS_REG(di);
+  d.w[ax] += ul2[k] * di;
   return d;
 }
 SSD SV2 chol6_solve_neg_pair(const Chol6& L, const SV2& b) {
@@ -328,13 +353,6 @@ SSD SV2 chol6_solve_neg_pair(const Chol6& L, const SV2& b) {
 // Opaque register copies of what the packed recursions read as scalars: the callee is optimised on its own before it
 // is inlined, and instcombine then widens 'splat (load float)' of neighbouring record fields into overlapping
 // <2 x float> loads, which pins the record in scratch after inlining.
-SSD JRec opaque_rec(const JRec& r) {
-  JRec o = r;
-  SS_REG(o.cs); SS_REG(o.sn); SS_REG(o.Dinv); SS_REG(o.u);
-#pragma unroll
-  for (int m = 0; m < 3; ++m) { SS_REG(o.Uw[m]); SS_REG(o.Uv[m]); }
-  return o;
-}
 struct LamPair { ssf2 a[3], b[3]; };
 // Part A needs the leg records (joints 3..7) only: the T columns and the unit impulses carried from the foot up to the pelvis.
 // Part B needs the spine records and the base factor as well: up the spine, base solve, down to the pelvis (G) and the foot

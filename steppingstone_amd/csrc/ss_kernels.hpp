@@ -4,8 +4,13 @@
 // HBM layout (structure of arrays, env index fastest so every field access of a wavefront is one coalesced
 // 256-byte transaction):
 //   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8 | ep_ret_lo
-//   istate [NI][Npad] int   : next_step_index, target_reached_count, elapsed, rng_ctr, flags
-//   terrain [20*6][Npad] float : terrain_info (touched only on reset / stone advance / get_state)
+//   istate [NI][Npad] int   : next_step_index, target_reached_count, elapsed, rng_ctr, flags, prov_from
+//   terrain [20*6][Npad] float : terrain_info rows of the stones k < prov_from; the stones from prov_from on are the provisional
+//                                straight flat path (x = 0.75 k, everything else 0; PHYSICS.md 6) BY DEFINITION and their rows are
+//                                not written: a reset sets prov_from = 0 instead of storing 120 words that are scattered over 120
+//                                rows -- at the benchmark's reset rate that was 1.0 MB of sector writes plus 1.2 MB of fill reads
+//                                per 4096-env step, a third of the launch's HBM traffic (round 3).  Touched on stone advance,
+//                                get_state / set_state and by create_temp_states only.
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
 #pragma once
 #include "ss_dynamics.hpp"
@@ -18,7 +23,7 @@ namespace ss {
 
 enum { F_POS = 0, F_QUAT = 3, F_VEL = 7, F_Q = 13, F_QD = 34, F_POT = 55, F_ZINIT = 56, F_EPRET = 57, F_NNDR = 58,
        F_STONE = 59, F_EPRET_LO = 59 + 24, NF = 59 + 24 + 1 };
-enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, NI = 5 };
+enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, I_PROV = 5, NI = 6 };
 constexpr int kNumStones = 20;
 constexpr float kDeg = 0.017453292519943295f;
 
@@ -102,8 +107,13 @@ SSD float draw_stone(const Params& P, const Knobs& K, int e, uint32_t& ctr, int 
   float yaw = yaw_sample(cell / SS_GRID), pitch = pitch_sample(cell % SS_GRID);
   const size_t np = (size_t)P.npad;
   float* T = P.terrain + e;
-  float px = T[((k - 1) * 6 + 0) * np], py = T[((k - 1) * 6 + 1) * np], pz = T[((k - 1) * 6 + 2) * np];
-  float phi = T[((k - 1) * 6 + 3) * np] + yaw;
+  // stones from prov_from on are provisional (not stored): the first draw of an episode (k = 3) starts from the provisional
+  // stone 2 and puts the provisional stones 0..2 into the table
+  int prov = P.istate[e + I_PROV * np];
+  const bool prev_stored = k - 1 < prov;
+  float px = prev_stored ? T[((k - 1) * 6 + 0) * np] : 0.75f * (float)(k - 1);
+  float py = prev_stored ? T[((k - 1) * 6 + 1) * np] : 0.f, pz = prev_stored ? T[((k - 1) * 6 + 2) * np] : 0.f;
+  float phi = (prev_stored ? T[((k - 1) * 6 + 3) * np] : 0.f) + yaw;
   float sp, cp, sph, cph;
   sincosf(pitch, &sp, &cp);
   sincosf(phi, &sph, &cph);
@@ -114,8 +124,15 @@ SSD float draw_stone(const Params& P, const Knobs& K, int e, uint32_t& ctr, int 
   out_t[0] = xt; out_t[1] = yt;
   stone_normal(phi, xt, yt, out_n);
   if (store) {
+#pragma unroll 1
+    for (int j = prov; j < k; ++j) {            // (rare: once per episode that gets past its second stone)
+      T[(j * 6 + 0) * np] = 0.75f * (float)j;
+#pragma unroll
+      for (int i = 1; i < 6; ++i) T[(j * 6 + i) * np] = 0.f;
+    }
     T[(k * 6 + 0) * np] = out_p[0]; T[(k * 6 + 1) * np] = out_p[1]; T[(k * 6 + 2) * np] = out_p[2];
     T[(k * 6 + 3) * np] = phi; T[(k * 6 + 4) * np] = xt; T[(k * 6 + 5) * np] = yt;
+    if (prov < k + 1) P.istate[e + I_PROV * np] = k + 1;
   }
   return dr;
 }
@@ -256,13 +273,7 @@ SSD void cache_from_terrain(const Params& P, int e, int n, Cache& c) {
 template <class Model>
 SSD void env_reset(const Params& P, int e, Dyn& s, Cache& c, uint32_t& ctr, float& pot, float& z_init, float& nn_dr) {
   const size_t np = (size_t)P.npad;
-  float* T = P.terrain + e;
-#pragma unroll 1
-  for (int k = 0; k < kNumStones; ++k) {
-    T[(k * 6 + 0) * np] = 0.75f * (float)k;
-#pragma unroll
-    for (int i = 1; i < 6; ++i) T[(k * 6 + i) * np] = 0.f;
-  }
+  P.istate[e + I_PROV * np] = 0;                // the whole path is provisional again: nothing is written to the terrain table
 #pragma unroll
   for (int sl = 0; sl < 3; ++sl) {
     c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
@@ -770,16 +781,8 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   const bool do_reset = d && K.auto_reset;
   uint32_t rr[6][4];
   if (do_reset) {
-    // PHYSICS.md section 7: provisional terrain, standing pose, joint noise from 6 Philox blocks
-    if (valid && side == 0) {
-      float* T = P.terrain + e;
-#pragma unroll 1
-      for (int k = 0; k < kNumStones; ++k) {
-        T[(k * 6 + 0) * np] = 0.75f * (float)k;
-#pragma unroll
-        for (int i = 1; i < 6; ++i) T[(k * 6 + i) * np] = 0.f;
-      }
-    }
+    // PHYSICS.md section 7: provisional terrain (prov_from = 0: no table writes), standing pose, joint noise from 6 Philox blocks
+    if (valid && side == 0) P.istate[e + I_PROV * np] = 0;
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
       c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
@@ -1061,7 +1064,8 @@ __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, con
     const int n = P.istate[e + I_N * np];
     if (n + 1 <= kNumStones - 1) {
       const float* T = P.terrain + e;
-      float phi = T[(n * 6 + 3) * np] + yaw_sample(cell / SS_GRID), pitch = pitch_sample(cell % SS_GRID);
+      const float phi_n = n < P.istate[e + I_PROV * np] ? T[(n * 6 + 3) * np] : 0.f;      // a provisional stone is not stored
+      float phi = phi_n + yaw_sample(cell / SS_GRID), pitch = pitch_sample(cell % SS_GRID);
       float dr = P.fstate[e + F_NNDR * np];
       float sp, cp, sph, cph;
       sincosf(pitch, &sp, &cp);
@@ -1143,7 +1147,11 @@ SSD void pack_env(const Params& P, int e, float* packed) {
   o[62] = (float)(ctr & 0xFFFFu);
   o[63] = (float)(ctr >> 16);
   o[64] = (float)P.istate[e + I_FLAGS * np];
-  for (int i = 0; i < 120; ++i) o[65 + i] = P.terrain[e + (size_t)i * np];
+  const int prov = P.istate[e + I_PROV * np];
+  for (int i = 0; i < 120; ++i) {
+    const int k = i / 6;
+    o[65 + i] = k < prov ? P.terrain[e + (size_t)i * np] : (i % 6 == 0 ? 0.75f * (float)k : 0.f);
+  }
   o[185] = P.fstate[e + (size_t)F_EPRET_LO * np];
 }
 SSD void unpack_env(const Params& P, int e, const float* packed) {
@@ -1157,6 +1165,7 @@ SSD void unpack_env(const Params& P, int e, const float* packed) {
   P.istate[e + I_RNG * np] = (int)((uint32_t)o[62] | ((uint32_t)o[63] << 16));
   P.istate[e + I_FLAGS * np] = (int)o[64];
   for (int i = 0; i < 120; ++i) P.terrain[e + (size_t)i * np] = o[65 + i];
+  P.istate[e + I_PROV * np] = kNumStones;        // an injected terrain is stored in full
   P.fstate[e + (size_t)F_EPRET_LO * np] = o[185];
   Cache c;
   cache_from_terrain(P, e, n, c);
