@@ -247,6 +247,9 @@ SSD JRec opaque_rec(const JRec& r) {
   o.Uw[0] = w0; o.Uw[1] = w1; o.Uw[2] = w2; o.Uv[0] = v0; o.Uv[1] = v1; o.Uv[2] = v2;
   return o;
 }
+#ifndef SS_PIN
+#define SS_PIN(J) ((J) == 7)
+#endif
 // two columns at once in packed f32: the unloaded down step applies the same joint operator to every column of T, so
 // a pair of columns shares each instruction (v_pk_*), coefficients broadcast
 template <class Model, int J>
@@ -255,7 +258,7 @@ SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
   constexpr float rx = Model::r[J][0], ry = Model::r[J][1], rz = Model::r[J][2];
   const JRec& r = jc.r[k];
   float c = r.cs, s = r.sn;
-  SS_REG(c); SS_REG(s);
+  if constexpr (SS_PIN(J)) { SS_REG(c); SS_REG(s); }
   SV2 d;
   d.w[ax] = p.w[ax];
   d.w[ai] = p.w[ai] * c + p.w[aj] * s;
@@ -276,7 +279,7 @@ SSD SV2 imp_down_pair(const JointCache& jc, const SV2& p) {
   // overlapping <2 x float> load, and the record then stays in scratch (the ankle record did: 32 B per helper lane stored and
   // re-loaded every substep and written back at the end of every launch)
   float uw0 = r.Uw[0], uw1 = r.Uw[1], uw2 = r.Uw[2], uv0 = r.Uv[0], uv1 = r.Uv[1], uv2 = r.Uv[2], di = r.Dinv;
-  SS_REG(uw0); SS_REG(uw1); SS_REG(uw2); SS_REG(uv0); SS_REG(uv1); SS_REG(uv2); SS_REG(di);
+  if constexpr (SS_PIN(J)) { SS_REG(uw0); SS_REG(uw1); SS_REG(uw2); SS_REG(uv0); SS_REG(uv1); SS_REG(uv2); SS_REG(di); }
   ssf2 dotv = d.w[0] * uw0 + d.w[1] * uw1 + d.w[2] * uw2 + d.v[0] * uv0 + d.v[1] * uv1 + d.v[2] * uv2;
   d.w[ax] -= dotv * di;
   return d;
@@ -289,9 +292,11 @@ SSD SV2 imp_up_pair(const JointCache& jc, ssf2* ul2, const SV2& p) {
   const JRec& r = jc.r[k];
   float c = r.cs, s = r.sn, di = r.Dinv;
   float uw[3] = {r.Uw[0], r.Uw[1], r.Uw[2]}, uv[3] = {r.Uv[0], r.Uv[1], r.Uv[2]};
-  SS_REG(c); SS_REG(s); SS_REG(di);
+  if constexpr (SS_PIN(J)) {
+    SS_REG(c); SS_REG(s); SS_REG(di);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { SS_REG(uw[i]); SS_REG(uv[i]); }
+    for (int i = 0; i < 3; ++i) { SS_REG(uw[i]); SS_REG(uv[i]); }
+  }
   const ssf2 u = -p.w[ax];
   ul2[k] = u;
   const ssf2 du = u * di;
@@ -317,7 +322,7 @@ SSD SV2 imp_down_pair_loaded(const JointCache& jc, const ssf2* ul2, const SV2& p
   const JRec& r = jc.r[k];
   SV2 d = imp_down_pair<Model, J>(jc, p);            // includes  - Dinv * (U . d)
   float di = r.Dinv;
-  SS_REG(di);
+  if constexpr (SS_PIN(J)) SS_REG(di);
   d.w[ax] += ul2[k] * di;
   return d;
 }

@@ -36,10 +36,17 @@ def _worker(rank, port, ret):
     # benchmark path too: more steps than the ring of gather buffers is deep (asynchronous collectives, batched waits)
     o2, r2, d2 = env.rollout_random(11, t0=100)
     out.append(np.concatenate([o2.numpy(), r2.numpy()[:, None], d2.numpy()[:, None].astype(np.float32)], 1))
+    proof = [env.verify_last_exchange()]                               # self-proof of the per-step exchange (bench.py)
     # chunked exchange (K steps per launch, one collective per chunk): 2 full chunks + a ragged one
     o3, r3, d3 = env.rollout_random_chunked(11, t0=200, chunk=4)
     out.append(np.concatenate([o3.numpy(), r3.numpy()[:, None], d3.numpy()[:, None].astype(np.float32)], 1))
+    proof.append(env.verify_last_exchange())                           # ... and of the chunked one
+    # a block that did not arrive as sent must be noticed by EVERY rank: rank 1 damages the copy it received from rank 0
+    if rank == 1:
+        env._chunk_all[env._last[1]].view(WORLD, -1, N_LOCAL, 62)[0, 0, 0, 3] += 1.0
+    proof.append(env.verify_last_exchange())
     ret[rank] = out
+    ret[100 + rank] = proof
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,3 +75,4 @@ def test_two_rank_sharding_equals_single_process():
         assert len(res[rank]) == len(ref)
         for a, b in zip(res[rank], ref):
             assert np.array_equal(a, b)
+        assert res[100 + rank] == [(True, WORLD), (True, WORLD), (False, WORLD)]

@@ -124,3 +124,8 @@ def test_bench_two_rank_path_runs_end_to_end_on_one_gpu():
     assert d["config"]["envs_total"] == 2048 and d["config"]["ranks"] == 2 and d["config"]["parallelism"] == "env-shard x2+allgather"
     assert "test_transport" in d["config"] and d["value"] > 0 and d["ms_per_step"] > 0
     assert "no_gather" in d and "per_step_gather" in d and d["roofline"]["frac"] > 0
+    # the self-proof of the exchange and the policy-in-the-loop row (round 3)
+    assert d["gather_verified"] is True and d["rccl_ranks"] == 2 and "rccl_version" in d and d["transport"] == "gloo"
+    assert d["per_step_gather"]["value"] > 0 and d["policy_in_the_loop"]["ms_per_step"] == d["per_step_gather"]["ms_per_step"]
+    assert d["repeats"] >= 1 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert "32-step" in d["config"]["value_is"] and "per 32-step chunk" in d["config"]["collective"]
