@@ -35,13 +35,14 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DStepperEnv-v0"
 # ALGORITHMIC HBM bytes per env-step with this repository's state layout:
-#   one launch per step: read 83 f32 state / stone-cache fields + 4 i32 = 348 B; write 59 f32 + 5 i32 state = 256 B,
-#                        obs 240 B, rew 4 B, done 1 B, info 20 B = 521 B                                     -> 869 B
-#   K steps per launch:  the 348 B are read once per launch, the 521 B written every step; the epilogue's re-read of
-#                        the 13 bookkeeping words + stone cache is served by L2                 -> 521 + 348/K B
-# roofline.achieved is computed from the 869 B per-unit figure for both launch shapes; the smaller figure of
+#   one launch per step: read 84 f32 state / stone-cache fields + 4 i32 = 352 B; write 60 f32 + 5 i32 state = 260 B,
+#                        obs 240 B, rew 4 B, done 1 B, info 24 B = 529 B                                     -> 881 B
+#   K steps per launch:  the 352 B are read once per launch, the 529 B written every step; the epilogue's re-read of
+#                        the 13 bookkeeping words + stone cache is served by L2                 -> 529 + 352/K B
+# (rounds 1-2: 348 + 521 = 869 B, before the second word of the episode return: ss_info.ep_ret_lo, fstate row 83.)
+# roofline.achieved is computed from the 881 B per-unit figure for both launch shapes; the smaller figure of
 # the K-step kernel and the PMC-measured traffic are reported beside it.
-ALGO_READ_B, ALGO_WRITE_B = 348, 521
+ALGO_READ_B, ALGO_WRITE_B = 352, 529
 HBM_PEAK_GBS = 8000.0
 VALU_FP32_PEAK_TFLOPS = 157.3          # packed-f32 vector peak (MI355X_MICROARCH.md): 256 CUs x 2.4 GHz x 256 flop/clk
 
@@ -447,8 +448,8 @@ def main():
         total_envs = n_local * world
         value = total_envs * K / elapsed
         steps_in_launch = spl if multi_step else (32 if chunked else 1)
-        # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (869 B per env-step: the state
-        # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 348 B
+        # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (881 B per env-step: the state
+        # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 352 B
         # of state are read once per launch): that figure is reported next to it, as is the PMC-measured traffic.
         algo_per_env_step = float(ALGO_WRITE_B + ALGO_READ_B)
         algo_k_step = ALGO_WRITE_B + ALGO_READ_B / float(steps_in_launch)

@@ -115,3 +115,29 @@ def test_adaptive_sampler_grid():
         assert p is not None and p.shape == (11, 11) and p.dtype == np.float64
         assert abs(p.sum() - 1.0) < 1e-6 and (p > 0).all()      # softmax is evaluated in fp32 like the reference
         envs.update_sample_prob(np.repeat(p[None], n, axis=0))      # what train.py:267-271 does
+
+
+def test_reference_checkpoint_loader():
+    """steppingstone_amd.legacy_checkpoint: the reference's shipped Walker3D policy (legacy torch.save of the pickled Policy
+    module) read with the restricted unpickler -- no reference code executed -- and mapped onto ActorCritic; the deterministic
+    action must equal a numpy forward pass over the raw arrays of the file (this container only: the file lives under
+    /root/reference)."""
+    import os
+    path = "/root/reference/playground/models/mocca_envs:Walker3DStepperEnv-v0_latest.pt"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    from steppingstone_amd import legacy_checkpoint as lc
+    ac = lc.load_reference_checkpoint(path)
+    obj, st = lc.read_legacy(path)
+    w = lc.tensors_of(obj, st)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(5, 60)).astype(np.float32)
+    h = x.astype(np.float64)
+    for i, act in ((1, "softsign"), (2, "softsign"), (3, "softsign"), (4, "relu"), (5, "relu")):
+        h = h @ w["actor.fc%d.weight" % i].T.astype(np.float64) + w["actor.fc%d.bias" % i]
+        h = h / (1 + np.abs(h)) if act == "softsign" else np.maximum(h, 0)
+    ref = np.tanh(h @ w["actor.out.weight"].T.astype(np.float64) + w["actor.out.bias"])
+    with torch.no_grad():
+        v, a, _ = ac.act(torch.from_numpy(x), deterministic=True)
+    assert np.abs(a.numpy() - ref).max() < 1e-5
+    assert np.allclose(ac.logstd.detach().numpy(), w["dist.logstd._bias"].reshape(-1)) and v.shape == (5, 1)

@@ -6,10 +6,7 @@ unpickler (no reference code is executed); nothing is written into the repositor
 
   python tools/shipped_policy_check.py [/root/reference/playground/models/mocca_envs:Walker3DStepperEnv-v0_latest.pt]
 """
-import collections
 import os
-import pickle
-import struct
 import sys
 
 import numpy as np
@@ -19,67 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 
-class _Stub:
-    def __init__(self, *a, **k):
-        pass
-
-    def __setstate__(self, st):
-        self.__dict__.update(st if isinstance(st, dict) else {})
-
-
-def _rebuild_tensor_v2(storage, offset, size, stride, *rest):
-    return ("tensor", storage, offset, tuple(size), tuple(stride))
-
-
-def _rebuild_parameter(data, requires_grad, hooks):
-    return data
-
-
-class _U(pickle.Unpickler):
-    def find_class(self, mod, name):
-        if (mod, name) == ("collections", "OrderedDict"):
-            return collections.OrderedDict
-        if (mod, name) == ("torch._utils", "_rebuild_tensor_v2"):
-            return _rebuild_tensor_v2
-        if (mod, name) == ("torch._utils", "_rebuild_parameter"):
-            return _rebuild_parameter
-        if mod == "torch" and name.endswith("Storage"):
-            return name
-        return _Stub          # model classes / backends -> inert stubs
-
-    def persistent_load(self, pid):
-        if pid[0] == "module":
-            return pid[1]
-        if pid[0] == "storage":
-            return ("storage", pid[2], pid[4])        # key, numel
-        raise pickle.UnpicklingError(pid)
-
-
-def read_legacy(path):
-    f = open(path, "rb")
-    for _ in range(3):
-        pickle.load(f)                                # magic, protocol, sys info
-    obj = _U(f).load()
-    keys = pickle.load(f)
-    storages = {}
-    for k in keys:
-        n = struct.unpack("<q", f.read(8))[0]
-        storages[k] = np.frombuffer(f.read(4 * n), dtype="<f4").copy()
-    return obj, storages
-
-
-def tensors_of(obj, storages, prefix="", out=None):
-    out = {} if out is None else out
-    d = getattr(obj, "__dict__", {})
-    for group in ("_parameters", "_buffers"):
-        for k, v in (d.get(group) or {}).items():
-            if isinstance(v, tuple) and v and v[0] == "tensor":
-                _, st, off, size, stride = v
-                flat = storages[st[1]]
-                out[prefix + k] = np.lib.stride_tricks.as_strided(flat[off:], size, [s * 4 for s in stride]).copy()
-    for k, m in (d.get("_modules") or {}).items():
-        tensors_of(m, storages, prefix + k + ".", out)
-    return out
+from steppingstone_amd.legacy_checkpoint import read_legacy, tensors_of  # noqa: E402
 
 
 def main():
