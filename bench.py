@@ -227,7 +227,7 @@ def cpu_baseline(budget=24.0):
 
 
 # ------------------------------------------------------------------------------------------------ the bench
-def launch_shape(W, K, spl, ms_per_step):
+def launch_shape(W, K, spl, ms_per_step, prewarm=0):
     """The launches of the dominant kernel in this run (warm-up and timed) and the per-launch average a `rocprofv3 --stats`
     summary of the same command shows for it: the warm-up launch is shorter than the timed ones, so that average is not
     `kernel_ms` (profiles/*_rocprofv3_rollout_dispatches.csv lists the dispatches one by one)."""
@@ -238,8 +238,8 @@ def launch_shape(W, K, spl, ms_per_step):
             n -= out[-1]
         return out
     warm, timed = sizes(W), sizes(K)
-    every = warm + timed
-    return {"launch_steps": {"warmup": warm, "timed": timed},
+    every = ([prewarm] if spl > 1 and prewarm else []) + warm + timed     # the clock-ramp launch runs the same kernel
+    return {"launch_steps": {"prewarm": prewarm, "warmup": warm, "timed": timed},
             "rocprofv3_stats_average_ms_expected": ms_per_step * sum(every) / max(len(every), 1)}
 
 
@@ -489,7 +489,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_model": tinfo,
                          "kernel": kernel, "kernel_ms": launch_ms, "kernel_ms_per_step": kernel_ms_per_step,
-                         **launch_shape(W, K, steps_in_launch, kernel_ms_per_step),
+                         **launch_shape(W, K * len(samples), steps_in_launch, kernel_ms_per_step, PREWARM if multi_step else 0),
                          "algorithmic_bytes_per_env_step": algo_per_env_step,
                          "algorithmic_bytes_per_launch": algo_per_launch,
                          "algorithmic_bytes_per_env_step_with_lds_resident_state": algo_k_step,
