@@ -277,11 +277,11 @@ class EpisodeRing:
             return self.values()
         import torch.distributed as dist
         w = _dist_world()
-        bufs = torch.zeros((w, self.size), device=self.buf.device, dtype=self.buf.dtype)
+        flat = torch.zeros(w * self.size, device=self.buf.device, dtype=self.buf.dtype)
         cnts = torch.zeros(w, dtype=torch.long, device=self.buf.device)
-        dist.all_gather_into_tensor(bufs, self.buf[:self.size].contiguous())
-        dist.all_gather_into_tensor(cnts, self.count.reshape(1))
-        bufs, cnts = bufs.cpu(), cnts.cpu().tolist()
+        dist.all_gather_into_tensor(flat, self.buf[:self.size].contiguous())
+        dist.all_gather_into_tensor(cnts, self.count.reshape(1).contiguous())
+        bufs, cnts = flat.view(w, self.size).cpu(), cnts.cpu().tolist()
         parts = [bufs[r] if c == self.size else bufs[r, :c] for r, c in enumerate(cnts) if c]
         return torch.cat(parts) if parts else torch.empty(0)
 
@@ -505,6 +505,11 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
         agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=use_graph)
     roll = Rollouts(num_steps, n, dev)
     ring = EpisodeRing(n, dev)
+    any_logger = logger is not None
+    if multi:                                             # one decision for all ranks: the CSV row needs a collective
+        flag = torch.tensor([1.0 if logger is not None else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        any_logger = bool(flag.item())
     curriculum = specialist = 0
     if use_curriculum:
         envs.update_curriculum(curriculum)
@@ -591,7 +596,8 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
                  "value_loss": vl, "action_loss": al, "mean_rew": mean_ret, "curriculum": curriculum,
                  "grid_updated": grid_updated}
         history.append(stats)
-        vals = ring.all_ranks_values() if (logger is not None and cnt > 1) else None     # collective: every rank calls it
+        # collective: EVERY rank calls it when any rank logs (only rank 0 holds a logger: steppingstone_amd/train.py)
+        vals = ring.all_ranks_values() if (any_logger and cnt > 1) else None
         if logger is not None and rank == 0 and cnt > 1 and vals.numel():      # train.py:564: only once episodes have finished
             logger.log_epoch({"iter": j + 1, "total_num_steps": frames, "fps": stats["fps"], "entropy": ent,
                               "value_loss": vl, "action_loss": al, "stats": {"rew": vals.numpy()},

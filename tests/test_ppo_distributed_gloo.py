@@ -140,9 +140,16 @@ def _train_worker(rank, port, ret):
     n = 6
     envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n, seed=8, return_numpy=False, env_id_offset=rank * n,
                                backend=OracleBackend(1, n, 8, env_id_offset=rank * n))
-    ac, hist = ppo.train(envs, num_updates=2, num_steps=8, ppo_epoch=2, mini_batch_size=24, log=None)
+    # only rank 0 holds a logger (as in steppingstone_amd/train.py): the CSV row's episode statistics are gathered from every
+    # rank, so the gather must be entered by the rank WITHOUT a logger too (it deadlocked when gated on `logger is not None`)
+    import tempfile
+    from steppingstone_amd.csv_logger import ConsoleCSVLogger
+    logdir = tempfile.mkdtemp() if rank == 0 else None
+    logger = ConsoleCSVLogger(log_dir=logdir, console_log_interval=1000) if rank == 0 else None
+    ac, hist = ppo.train(envs, num_updates=3, num_steps=24, ppo_epoch=2, mini_batch_size=24, log=None, logger=logger)
+    rows = len(open(os.path.join(logdir, "progress.csv")).read().strip().splitlines()) - 1 if rank == 0 else -1
     ret[rank] = (torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy(), [h["curriculum"] for h in hist],
-                 hist[-1]["total_num_steps"], [h["mean_rew"] for h in hist])
+                 hist[-1]["total_num_steps"], [h["mean_rew"] for h in hist], rows)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -154,5 +161,6 @@ def test_train_under_two_ranks_keeps_replicas_identical():
         mp.spawn(_train_worker, args=(port, ret), nprocs=WORLD, join=True)
         res = {k: v for k, v in ret.items()}
     assert np.array_equal(res[0][0], res[1][0])
-    assert res[0][1] == res[1][1] and res[0][2] == 2 * 8 * 6 * WORLD
+    assert res[0][1] == res[1][1] and res[0][2] == 3 * 24 * 6 * WORLD
+    assert res[0][4] >= 1                                             # rank 0 wrote CSV rows; nobody hung
     assert np.allclose(res[0][3], res[1][3], equal_nan=True)          # the gate statistic is all-reduced: same on every rank
