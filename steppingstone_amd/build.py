@@ -11,7 +11,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libsteppingstone.so")
-SOURCES = ["ss_api.hip"]
+SOURCES = ["ss_api.hip", "ss_rollout3.hip"]
+# ss_rollout3.hip (the three-helper rollout kernel) is compiled without the max-ILP scheduling strategy: see its header
+NO_MAX_ILP = {"ss_rollout3.hip"}
 HEADERS = ["ss_math.hpp", "ss_pair.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "ss_model_tables.hpp",
            os.path.join("..", "..", "include", "steppingstone.h")]
 # -O3 without the SLP vectorizer, signed zeros not honoured.  Measured on gfx950 / ROCm 7.2:
@@ -27,7 +29,7 @@ HEADERS = ["ss_math.hpp", "ss_pair.hpp", "ss_dynamics.hpp", "ss_kernels.hpp", "s
 #     variants (with / without helper wavefronts) then round identically, so results do not depend on batch size or on
 #     the number of GPUs a batch is sharded over (bitwise; tested).  Costs 3 % on the plain variant, nothing on the
 #     helper variant.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize", "-fno-signed-zeros",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fno-signed-zeros",
          "-ffp-contract=on"]
 # scheduling only (no effect on values): the max-ILP machine scheduler is worth 1.4 % on the step kernel.  It is an
 # -mllvm option, so build() falls back to the plain flags if a compiler does not know it.
@@ -70,15 +72,28 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    tail = [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    for flags in (FLAGS + OPTIONAL_FLAGS, FLAGS):
-        cmd = [hipcc()] + flags + tail
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src, with_optional):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + FLAGS + (OPTIONAL_FLAGS if with_optional else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        if flags is FLAGS:
-            subprocess.check_call(cmd)
-        elif subprocess.call(cmd, stderr=subprocess.DEVNULL) == 0:
+        return obj, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)
+
+    # the translation units compile in parallel; a compiler that does not know the optional -mllvm flag gets the plain flags
+    for with_optional in (True, False):
+        jobs = [compile_one(src, with_optional and src not in NO_MAX_ILP) for src in SOURCES]
+        rcs = [p.wait() for _, p in jobs]
+        if all(rc == 0 for rc in rcs):
             break
+        if not with_optional:
+            raise subprocess.CalledProcessError(max(rcs), "hipcc -c")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in jobs] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
     return LIB
 
 

@@ -10,6 +10,11 @@
 
 #include "ss_kernels.hpp"
 
+// compiled in ss_rollout3.hip (its own scheduling strategy, see there)
+extern template __global__ void ss::rollout_kernel_helped<ss::ModelWalker3D, 3>(ss::Params, ss::StepIO);
+extern template __global__ void ss::rollout_kernel_helped<ss::ModelMike, 3>(ss::Params, ss::StepIO);
+
+
 namespace {
 
 thread_local std::string g_err;

@@ -952,10 +952,12 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
 }
 #endif  // SS_HOST_HARNESS
 
+// (The non-template kernels of this header are `static`: the header is included by two translation units, ss_api.hip and
+// ss_rollout3.hip, and only ss_api.hip launches them.)
 // Consumer side of the peer-store all-gather: lane r waits until peer r has published `value` (or a later step) in this
 // rank's flag array.  Bounded spin: on time-out it raises *error instead of hanging the GPU.
 #ifndef SS_HOST_HARNESS
-__global__ void peer_wait_kernel(const uint32_t* flags, int count, uint32_t value, uint32_t* error) {
+static __global__ void peer_wait_kernel(const uint32_t* flags, int count, uint32_t value, uint32_t* error) {
   const int r = threadIdx.x;
   if (r >= count) return;
   for (long long it = 0; it < (1ll << 23); ++it) {     // ~1 s
@@ -969,17 +971,17 @@ __global__ void peer_wait_kernel(const uint32_t* flags, int count, uint32_t valu
 
 // hook updates, stream-ordered (ss_api.hip)
 #ifndef SS_HOST_HARNESS
-__global__ void set_knobs_kernel(Knobs* dst, Knobs v) {
+static __global__ void set_knobs_kernel(Knobs* dst, Knobs v) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
 }
 // per-env sampling grids: [N][121] row-major (the caller's layout, playground/train.py:267-271) -> [121][Npad]
-__global__ void transpose_prob_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int npad) {
+static __global__ void transpose_prob_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int npad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * SS_NCELL) return;
   const int e = i / SS_NCELL, k = i - e * SS_NCELL;
   dst[(size_t)k * npad + e] = src[i];
 }
-__global__ void copy_prob_kernel(const float* __restrict__ src, float* __restrict__ dst) {
+static __global__ void copy_prob_kernel(const float* __restrict__ src, float* __restrict__ dst) {
   if (threadIdx.x < SS_NCELL) dst[threadIdx.x] = src[threadIdx.x];
 }
 #endif
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(kWave) void obs_kernel(Params P, float* obs) {
 #define SS_TEMP_THREADS 240            // a multiple of 15: every thread keeps ONE float4 column of the row
 #endif
 constexpr int kTempThreads = SS_TEMP_THREADS;
-__global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, const float* __restrict__ obs_rows, float* out) {
+static __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, const float* __restrict__ obs_rows, float* out) {
   __shared__ __attribute__((aligned(16))) float base[SS_OBS_DIM];
   __shared__ float feat[SS_NCELL * 5];
   const int e = blockIdx.x, t = threadIdx.x;
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(kTempThreads) void temp_states_kernel(Params P, con
 #endif  // SS_HOST_HARNESS
 
 #ifndef SS_HOST_HARNESS
-__global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
+static __global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= P.n) return;
 #pragma unroll
@@ -1129,7 +1131,7 @@ __global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
 
 #ifndef SS_HOST_HARNESS
 // PMC calibration: a dword-per-lane coalesced copy with the step kernel's access shape (tools/hbm_traffic.py)
-__global__ void calib_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+static __global__ void calib_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] + 1.0f;
 }
@@ -1172,13 +1174,13 @@ SSD void unpack_env(const Params& P, int e, const float* packed) {
   store_cache(P, e, c);
 }
 #ifndef SS_HOST_HARNESS
-__global__ void pack_state_kernel(Params P, float* packed) {
+static __global__ void pack_state_kernel(Params P, float* packed) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < P.n) pack_env(P, e, packed);
 }
 #endif  // SS_HOST_HARNESS
 #ifndef SS_HOST_HARNESS
-__global__ void unpack_state_kernel(Params P, const float* packed) {
+static __global__ void unpack_state_kernel(Params P, const float* packed) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < P.n) unpack_env(P, e, packed);
 }

@@ -1,0 +1,14 @@
+// ss_rollout3.hip -- the three-helper rollout kernel (BASELINE's 4096 envs per GPU) as its own translation unit.
+//
+// Why: machine-scheduling strategy is a per-translation-unit compiler option.  The max-ILP strategy is worth 7.5 % on the plain
+// kernel (32768 envs: 0.0683 vs 0.0734 ms/step) and 3.5 % on the single-helper one, but costs the three-helper ROLLOUT kernel 1.7 %
+// (0.0498 vs 0.0490 ms/step at 4096 envs, three interleaved runs each; the one-launch-per-step kernel does not care).  Scheduling
+// reorders independent instructions only: the values are the same bits whichever strategy compiled a kernel (the bitwise tests of
+// tests/test_gpu_branches.py compare this kernel with the others).  steppingstone_amd/build.py compiles this file WITHOUT
+// -amdgpu-sched-strategy=max-ilp and everything else (ss_api.hip) with it; ss_api.hip declares these two instantiations extern.
+#include <hip/hip_runtime.h>
+
+#include "ss_kernels.hpp"
+
+template __global__ void ss::rollout_kernel_helped<ss::ModelWalker3D, 3>(ss::Params, ss::StepIO);
+template __global__ void ss::rollout_kernel_helped<ss::ModelMike, 3>(ss::Params, ss::StepIO);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B timing of kernel build variants on the GPU box.  usage: tools/ab_variants.sh name1:"-DX=1" name2:"-DY" ...
+# (Both translation units get the same flags here, max-ILP scheduling included: the in-tree build compiles ss_rollout3.hip without it.)
 # Builds each variant into var/ (git-ignored, travels with the gpurun snapshot), then one gpurun call runs the
 # configs[1] bench on every variant (and the in-tree build) twice, interleaved.
 cd "$(dirname "$0")/.." || exit 1
@@ -8,7 +9,7 @@ names=()
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -fno-signed-zeros -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp $flags \
-    -Rpass-analysis=kernel-resource-usage steppingstone_amd/csrc/ss_api.hip -o var/libss_$name.so 2> var/$name.res || { echo "build $name failed"; exit 1; }
+    -Rpass-analysis=kernel-resource-usage steppingstone_amd/csrc/ss_api.hip steppingstone_amd/csrc/ss_rollout3.hip -o var/libss_$name.so 2> var/$name.res || { echo "build $name failed"; exit 1; }
   printf "%-12s " "$name"; grep -A12 "step_kernelINS_13ModelWalker3DELb1" var/$name.res | grep -E "VGPRs:|AGPRs|ScratchSize" | sed 's/.*remark: *//; s/ \[-R.*//' | tr '\n' ' '; echo
   names+=("$name")
 done
