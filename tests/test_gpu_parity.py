@@ -103,7 +103,12 @@ def _assert_judged(R, txt, label):
     plain = R["category"] == 0
     assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 6 s <= 1e-4
     assert R["int_excused"].mean() < 1e-3
-    assert np.quantile(R["e_obs"], 0.99) < 1e-4                                      # all env-steps, against the oracle as it ran
+    # all env-steps, against the oracle as it ran: 99 % within the north-star's 1e-4 (measured: 99 % within 2e-5), at most 0.5 % beyond it
+    assert np.quantile(R["e_obs"], 0.99) < 1e-4 and (R["e_obs"] > 1e-4).mean() < 5e-3
+    # ... and against the fp64 evaluation the kernel is no noisier than the CPU's own fp32 build (which also leaves 1e-4 on ~0.16 %)
+    far_hip, far_cpu = int((R["e_hip_o64"] > 1e-4).sum()), int((R["e_o32_o64"] > 1e-4).sum())
+    print("   env-steps farther than 1e-4 from the fp64 oracle: HIP kernel %d, fp32 CPU oracle %d (of %d)" % (far_hip, far_cpu, R["ok"].size))
+    assert far_hip <= 1.5 * far_cpu + 8
 
 
 def _judged_step(J, g, st, a):
