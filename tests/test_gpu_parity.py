@@ -397,6 +397,9 @@ def test_bench_rccl_path_on_one_rank():
     assert js["config"]["parallelism"].endswith("+allgather")
     assert js["value"] > 1e6 and js["n_gpus"] == 1
     assert js["no_gather"]["ms_per_step"] > 0 and js["peer_store"]["ms_per_step"] > 0 and js["peer_store"]["wait_timeouts"] == 0
+    # the exchange proved itself over real RCCL (one rank: the rank's own block came back as sent), and says what it ran on
+    assert js["gather_verified"] is True and js["rccl_ranks"] == 1 and js["transport"] == "nccl (RCCL)" and js["rccl_version"]
+    assert js["per_step_gather"]["value"] > 0 and "all-gather of [N/G,62]" in js["policy_in_the_loop"]["what"]
 
 
 def test_ppo_graph_replay_matches_eager():
