@@ -4,19 +4,19 @@ against the CPU oracle.  TEST INFRASTRUCTURE (imports oracle_lib).
 Every env-step is bounded -- none passes on an allowance:
 
   integers (next_step_index, counters, RNG counter, contact flags, done, bad_transition, update_terrain): bit-exact;
-  observation: |obs_hip - obs_oracle| <= max(1e-4, 6 s)      (1e-4 = the north-star's per-step bound)
-  reward:      |rew_hip - rew_oracle| <= max(1e-3, 6 s_rew)
+  observation: |obs_hip - obs_oracle| <= max(1e-4, 8 s)      (1e-4 = the north-star's per-step bound)
+  reward:      |rew_hip - rew_oracle| <= max(1e-3, 8 s_rew)
 
 where s is the MEASURED first-order sensitivity of that very env-step in the fp64 build of the oracle: each of the 55
 dynamic state inputs (base pose / twist, q, qd) is perturbed by 8 ulp (relative 8 * 2^-23, floor 1e-3 absolute scale), one
 at a time, and the absolute changes of the observation are summed per component (a first-order worst case over the
 signs of the input errors); s also includes the distance between the oracle's own fp32 and fp64 builds on that step.  An
-env-step with 6 s <= 1e-4 is "plain" and held to the north-star's 1e-4; one with 6 s > 1e-4 ("sensitive": the light
+env-step with 8 s <= 1e-4 is "plain" and held to the north-star's 1e-4; one with 8 s > 1e-4 ("sensitive": the light
 foot / ankle pivoting on one or two sole corners amplifies rounding 1e2..1e5 x within the four substeps, measured on the
-CPU alone) is held to 6 x what the specification itself does to an 8-ulp input error.  The classification never looks at
-the HIP result.  Calibration (163 840 env-steps, both robots, flat and curriculum-5 terrain, round-3 kernels): the largest
-|obs| error over s is 3.7; the largest error of a plain env-step is 5e-5; 64 % of env-steps are plain, the median bound of
-the others is 2e-4.  The fp32 oracle itself is farther than 1e-4 from its fp64 build on 0.16 % of env-steps (the kernel:
+CPU alone) is held to 8 x what the specification itself does to an 8-ulp input error.  The classification never looks at
+the HIP result.  Calibration (tools/parity_rule_stats.py: 327 680 env-steps, both robots, flat and curriculum-5 terrain,
+round-3 kernels): the largest |obs| error over s is 5.4 (99.9 % of env-steps: below 0.9), hence the factor 8; about 60 % of
+env-steps are plain, the bound of the others is 2.8e-4 at the 90 % and 1e-3 at the 99 % quantile of all env-steps.  The fp32 oracle itself is farther than 1e-4 from its fp64 build on 0.16 % of env-steps (the kernel:
 0.17 %), so no fp32 implementation can hold 1e-4 on every step -- hence a bound that scales with the step's own
 conditioning rather than a blanket allowance.
 
@@ -35,7 +35,7 @@ import numpy as np
 import oracle_lib as ol
 
 OBS_TOL, REW_TOL, NEAR_TOL = 1e-4, 1e-3, 1e-5
-ULPS, SENS_FACTOR = 8.0, 6.0
+ULPS, SENS_FACTOR = 8.0, 8.0
 MAX_DEPTH, MAX_ALTERNATIVES = 3, 24
 NDYN = 55                                   # pos 3, quat 4, twist 6, q 21, qd 21 of the packed state
 INT_FIELDS = [ol.S_N, ol.S_COUNT, ol.S_ELAPSED, ol.S_CTRLO, ol.S_CTRHI, ol.S_FLAGS]

@@ -5,7 +5,7 @@ Tolerances (fp32, stated here as required by the task brief; the rule itself is 
   * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, contact flags,
     done, bad_transition, update_terrain): bit-exact;
   * one control step from an identical injected state (4 substeps, different operation order, own sincos / reciprocal):
-    EVERY env-step is bounded by |obs| error <= max(1e-4, 6 s), |rew| error <= max(1e-3, 6 s_rew), where 1e-4 is the
+    EVERY env-step is bounded by |obs| error <= max(1e-4, 8 s), |rew| error <= max(1e-3, 8 s_rew), where 1e-4 is the
     north-star's per-step bound and s is the measured first-order response of the fp64 oracle to an 8-ulp error in
     each of that step's 55 dynamic state inputs (summed); an env-step whose oracle evaluation has a discrete decision
     within 1e-5 of its threshold must match the oracle re-evaluated on one of the alternative branches (integers
@@ -101,7 +101,7 @@ def _assert_judged(R, txt, label):
         np.array2string(np.quantile(R["tol"], [.5, .9, .99, 1.0]), precision=2), np.array2string(np.quantile(R["e_obs"], [.5, .9, .99, 1.0]), precision=2)))
     assert R["ok"].all(), "%d env-steps outside their bound" % (~R["ok"]).sum()
     plain = R["category"] == 0
-    assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 6 s <= 1e-4
+    assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 8 s <= 1e-4
     assert R["int_excused"].mean() < 1e-3
     # all env-steps, against the oracle as it ran: 99 % within the north-star's 1e-4 (measured: 99 % within 2e-5), at most 0.5 % beyond it
     assert np.quantile(R["e_obs"], 0.99) < 1e-4 and (R["e_obs"] > 1e-4).mean() < 5e-3
