@@ -191,6 +191,7 @@ class SteppingStoneVecEnv:
             self._pinned = {"act": torch.zeros((n, ACT_DIM), dtype=torch.float32).pin_memory(),
                             "out": torch.zeros((n, OBS_DIM + 2), dtype=torch.float32).pin_memory(),
                             "dev": torch.zeros((n, OBS_DIM + 2), dtype=torch.float32, device=dev),
+                            "info": torch.zeros((n, INFO_WORDS), dtype=torch.int32).pin_memory(),
                             "event": torch.cuda.Event()}
         self._tstart = time.time()
         self.yaw_samples = np.linspace(-20.0, 20.0, GRID) * DEG
@@ -217,6 +218,7 @@ class SteppingStoneVecEnv:
             self._act.copy_(pb["act"], non_blocking=True)
             self.backend.step_packed(self._act, False, 0, pb["dev"], self._info)
             pb["out"].copy_(pb["dev"], non_blocking=True)
+            pb["info"].copy_(self._info, non_blocking=True)      # the step report travels with the block: no second, synchronous copy
             pb["event"].record()
             self._pending = "pinned"
             return
@@ -238,7 +240,7 @@ class SteppingStoneVecEnv:
             obs = out[:, :OBS_DIM].copy()                       # fresh arrays every step, like common/envs_utils.py:619
             rew = out[:, OBS_DIM].astype(np.float64)
             done = out[:, OBS_DIM + 1] > 0.5
-            return obs, rew, done, self._info_dicts(done)
+            return obs, rew, done, self._info_dicts(done, pb["info"].numpy())
         self._pending = False
         if not self.return_numpy:
             return self._obs, self._rew, self._done.bool(), self._info_tensors()
@@ -381,20 +383,25 @@ class SteppingStoneVecEnv:
         return {"ep_ret": fl[:, 0], "ep_len": fl[:, 1], "bad_transition": self._info[:, 2],
                 "steps_reached": self._info[:, 3], "update_terrain": self._info[:, 4], "ep_ret_lo": fl[:, 5]}
 
-    def _info_dicts(self, done):
-        """Sequence of N info dicts with the reference's keys (common/envs_utils.py:59-65,131-153)."""
+    def _info_dicts(self, done, raw=None):
+        """Sequence of N info dicts with the reference's keys (common/envs_utils.py:59-65,131-153).  raw: the [N,6] info words
+        on the host already (numpy drop-in mode); else they are fetched when any env finished."""
         infos = [_EMPTY_INFO] * self.num_envs
         idx = np.nonzero(done)[0]
         if idx.size:
-            raw = self._info.cpu().numpy()
+            if raw is None:
+                raw = self._info.cpu().numpy()
             fl = raw.view(np.float32)
             now = round(time.time() - self._tstart, 6)
-            for i in idx:
-                # Monitor.update: eprew = sum(self.rewards) in Python floats, "r": round(eprew, 6) (common/envs_utils.py:134-138);
-                # the kernel's (ep_ret, ep_ret_lo) pair is that fp64 sum of the fp32 step rewards
-                d = {"episode": {"r": round(float(fl[i, 0]) + float(fl[i, 5]), 6), "l": int(fl[i, 1]), "t": now},
-                     "steps_reached": int(raw[i, 3])}
-                if raw[i, 2]:
+            # Monitor.update: eprew = sum(self.rewards) in Python floats, "r": round(eprew, 6) (common/envs_utils.py:134-138); the
+            # kernel's (ep_ret, ep_ret_lo) pair is that fp64 sum of the fp32 step rewards.  Columns are pulled out as Python lists
+            # once (per-element numpy indexing made this loop 200 us per step at 4096 envs, two thirds of the drop-in mode's step).
+            rets = (fl[idx, 0].astype(np.float64) + fl[idx, 5].astype(np.float64)).tolist()
+            lens = fl[idx, 1].astype(np.int64).tolist()
+            bad, reached = raw[idx, 2].tolist(), raw[idx, 3].tolist()
+            for k, i in enumerate(idx.tolist()):
+                d = {"episode": {"r": round(rets[k], 6), "l": lens[k], "t": now}, "steps_reached": reached[k]}
+                if bad[k]:
                     d["bad_transition"] = True
                 infos[i] = d
         return tuple(infos)
