@@ -351,100 +351,6 @@ SSD SV2 chol6_solve_neg_pair(const Chol6& L, const SV2& b) {
   return x;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Pass 2 of the ABA, one joint step in two halves.  The articulated INERTIAS depend on the joint angles only (and on which
-// joint limits are engaged: the implicit diagonal Dadd): `aba_inertia` consumes the child's articulated inertia (child
-// coordinates), leaves the inertia half of the joint record (U = I S, 1 / (S.U + Dadd)), turns I into I^a = I - U U^T / D in place
-// and returns it in parent coordinates.  The BIAS forces need the velocities and the joint torques as well: `aba_bias` takes I^a
-// and the record, fills in u = tau - S.p and returns p^a = p + I^a c + U u / D in parent coordinates.  The plain kernel runs
-// both on the main wavefront, one after the other; with three helper wavefronts helper 0 runs the inertia chain of the whole
-// half tree and the main wavefront only the bias chain (records through LDS, below).  Same expressions, same bits.
-struct JRec2 { ssf2 Uw[3], Uv[3], Dinv, u; };     // the record of a {leg, arm} joint pair
-template <class Model, int J>
-SSD void aba_inertia(ABI& I, float Dadd, JRec& r, ABI& Ip) {
-  constexpr int ax = kAxis[J];
-  r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
-  r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
-  r.Dinv = SS_RCP(r.Uw[ax] + Dadd);
-  const float* Uw = r.Uw;
-  const float* Uv = r.Uv;
-  float sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
-  float sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
-  I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
-  I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
-  I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
-  I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
-  Ip = xinertia<Model, J>(r.cs, r.sn, I);
-}
-template <class Model, int J>
-SSD SV aba_bias(const ABI& I, JRec& r, float tau, float qd, const SV& vb, const SV& pA) {
-  constexpr int ax = kAxis[J], ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-  r.u = tau - pA.w[ax];
-  const float* Uw = r.Uw;
-  const float* Uv = r.Uv;
-  float cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
-  float cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
-  float du = r.Dinv * r.u;
-  SV pa;
-  {
-    const Sym3 &A = I.A, &C = I.C;
-    float Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
-    float Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
-      pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
-    }
-  }
-  return xforce<Model, J>(r.cs, r.sn, pa);
-}
-template <class Model, int JL, int JA>
-SSD void aba_inertiaP(ABIP& I, float Daddl, float Dadda, ssf2 c, ssf2 s, JRec2& r, ABIP& Ip) {
-  constexpr int ax = kAxis[JL];
-  r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
-  r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
-  const ssf2 D = r.Uw[ax] + pkv(Daddl, Dadda);
-  r.Dinv = pkv(SS_RCP(D.x), SS_RCP(D.y));
-  const ssf2* Uw = r.Uw;
-  const ssf2* Uv = r.Uv;
-  ssf2 sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
-  ssf2 sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
-  I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
-  I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
-  I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
-  I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc) I.B[a][cc] -= sw[a] * Uv[cc];
-  Ip = xinertiaP<Model, JL, JA>(c, s, I);
-}
-template <class Model, int JL, int JA>
-SSD SV2 aba_biasP(const ABIP& I, JRec2& r, float taul, float taua, ssf2 qd, ssf2 c, ssf2 s, const SV2& vb, const SV2& pA) {
-  constexpr int ax = kAxis[JL], ai = (ax + 1) % 3, aj = (ax + 2) % 3;
-  r.u = pkv(taul, taua) - pA.w[ax];
-  const ssf2* Uw = r.Uw;
-  const ssf2* Uv = r.Uv;
-  ssf2 cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
-  ssf2 cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
-  ssf2 du = r.Dinv * r.u;
-  SV2 pa;
-  {
-    const Sym3P &A = I.A, &C = I.C;
-    ssf2 Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
-    ssf2 Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
-      pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
-    }
-  }
-  return xforceP<Model, JL, JA>(c, s, pa);
-}
 
 // Contact-space operators for the column pair (2c, 2c+1): T = K = P_7 ... P_3 (own-foot twist per unit pelvis twist through
 // the unloaded leg; LDS), and by unit impulses on the own foot through the whole tree G (pelvis twist; LDS) and
@@ -917,21 +823,89 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     // one scalar joint: consumes the articulated inertia / bias of its child body, leaves the joint record, returns the
     // contribution to the parent (parent coordinates)
     auto joint_scalar = [&](auto Jc, ABI I, const SV& pA, const SV& vb, ABI& Ip, SV& pp) {
-      constexpr int j = decltype(Jc)::value, k = half_pos(j);
+      constexpr int j = decltype(Jc)::value, k = half_pos(j), ax = kAxis[j];
+      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       float tau, Dadd;
       tau_of(Jc, std::integral_constant<int, k>{}, tau, Dadd);
-      aba_inertia<Model, j>(I, Dadd, jc.r[k], Ip);
-      pp = aba_bias<Model, j>(I, jc.r[k], tau, qd_all[k], vb, pA);
+      const float qd = qd_all[k];
+      JRec& r = jc.r[k];
+      r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
+      r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
+      r.Dinv = SS_RCP(r.Uw[ax] + Dadd);
+      r.u = tau - pA.w[ax];
+      const float* Uw = r.Uw;
+      const float* Uv = r.Uv;
+      float sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
+      float sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
+      I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
+      I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
+      I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
+      I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
+      float cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
+      float cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
+      float du = r.Dinv * r.u;
+      SV pa;
+      {
+        const Sym3 &A = I.A, &C = I.C;
+        float Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
+        float Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
+          pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
+        }
+      }
+      Ip = xinertia<Model, j>(r.cs, r.sn, I);
+      pp = xforce<Model, j>(r.cs, r.sn, pa);
     };
+    struct JRec2 { ssf2 Uw[3], Uv[3], Dinv, u; };
     JRec2 jr2[4];
     auto joint_pair = [&](auto Ic, ABIP I, const SV2& pA, ABIP& Ip, SV2& pp) {
-      constexpr int i = decltype(Ic)::value, jl = 3 + i, ja = 13 + i, kl = 3 + i, ka = 8 + i;
+      constexpr int i = decltype(Ic)::value, jl = 3 + i, ja = 13 + i, kl = 3 + i, ka = 8 + i, ax = kAxis[jl];
+      constexpr int ai = (ax + 1) % 3, aj = (ax + 2) % 3;
       float taul, Daddl, taua, Dadda;
       tau_of(std::integral_constant<int, jl>{}, std::integral_constant<int, kl>{}, taul, Daddl);
       tau_of(std::integral_constant<int, ja>{}, std::integral_constant<int, ka>{}, taua, Dadda);
+      const ssf2 qd = qd2[i];
+      const SV2& vb = vp[i];
       JRec2& r = jr2[i];
-      aba_inertiaP<Model, jl, ja>(I, Daddl, Dadda, c2[i], s2[i], r, Ip);
-      pp = aba_biasP<Model, jl, ja>(I, r, taul, taua, qd2[i], c2[i], s2[i], vp[i], pA);
+      r.Uw[0] = I.A.template get<0, ax>(); r.Uw[1] = I.A.template get<1, ax>(); r.Uw[2] = I.A.template get<2, ax>();
+      r.Uv[0] = I.B[ax][0]; r.Uv[1] = I.B[ax][1]; r.Uv[2] = I.B[ax][2];
+      const ssf2 D = r.Uw[ax] + pkv(Daddl, Dadda);
+      r.Dinv = pkv(SS_RCP(D.x), SS_RCP(D.y));
+      r.u = pkv(taul, taua) - pA.w[ax];
+      const ssf2* Uw = r.Uw;
+      const ssf2* Uv = r.Uv;
+      ssf2 sw[3] = {r.Dinv * Uw[0], r.Dinv * Uw[1], r.Dinv * Uw[2]};
+      ssf2 sv[3] = {r.Dinv * Uv[0], r.Dinv * Uv[1], r.Dinv * Uv[2]};
+      I.A.m[0] -= sw[0] * Uw[0]; I.A.m[1] -= sw[1] * Uw[1]; I.A.m[2] -= sw[2] * Uw[2];
+      I.A.m[3] -= sw[0] * Uw[1]; I.A.m[4] -= sw[0] * Uw[2]; I.A.m[5] -= sw[1] * Uw[2];
+      I.C.m[0] -= sv[0] * Uv[0]; I.C.m[1] -= sv[1] * Uv[1]; I.C.m[2] -= sv[2] * Uv[2];
+      I.C.m[3] -= sv[0] * Uv[1]; I.C.m[4] -= sv[0] * Uv[2]; I.C.m[5] -= sv[1] * Uv[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I.B[a][c] -= sw[a] * Uv[c];
+      ssf2 cwi = qd * vb.w[aj], cwj = -qd * vb.w[ai];
+      ssf2 cvi = qd * vb.v[aj], cvj = -qd * vb.v[ai];
+      ssf2 du = r.Dinv * r.u;
+      SV2 pa;
+      {
+        const Sym3P &A = I.A, &C = I.C;
+        ssf2 Af[3][3] = {{A.m[0], A.m[3], A.m[4]}, {A.m[3], A.m[1], A.m[5]}, {A.m[4], A.m[5], A.m[2]}};
+        ssf2 Cf[3][3] = {{C.m[0], C.m[3], C.m[4]}, {C.m[3], C.m[1], C.m[5]}, {C.m[4], C.m[5], C.m[2]}};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          pa.w[rr] = pA.w[rr] + Af[rr][ai] * cwi + Af[rr][aj] * cwj + I.B[rr][ai] * cvi + I.B[rr][aj] * cvj + Uw[rr] * du;
+          pa.v[rr] = pA.v[rr] + I.B[ai][rr] * cwi + I.B[aj][rr] * cwj + Cf[rr][ai] * cvi + Cf[rr][aj] * cvj + Uv[rr] * du;
+        }
+      }
+      Ip = xinertiaP<Model, jl, ja>(c2[i], s2[i], I);
+      pp = xforceP<Model, jl, ja>(c2[i], s2[i], pa);
       // scalar joint records for the contact stage (sub-register views of the pairs)
       JRec& rl = jc.r[kl];
       JRec& ra = jc.r[ka];
