@@ -9,15 +9,16 @@ from steppingstone_amd.envs import SteppingStoneVecEnv
 NAMES = ["loop/entry", "sincos", "pass1 vel", "pass2 ABI", "base chol", "pass3 acc", "detect FK", "Linv 12 cols",
          "Vfree+rows", "PGS x8", "final resp", "integrate", "after loop", "reward/obs/store", "", ""]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+spl = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # steps per launch (0: library default; 1: the one-launch-per-step kernel)
 steps = 200
 env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=0, device="cuda:0")
 env.reset()
 lib = _lib.load()
 lib.ss_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 out = np.zeros(16, np.uint64)
-env.rollout_random(50, 0)
+env.rollout_random(50, 0, steps_per_launch=spl)
 lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
-env.rollout_random(steps, 50)
+env.rollout_random(steps, 50, steps_per_launch=spl)
 lib.ss_debug_phase_cycles(env.backend.h, out.ctypes.data_as(C.c_void_p), 1)
 waves = (n + 31) // 32      # two lanes per env: 32 envs per wavefront
 per = out.astype(np.float64) / (waves * steps)
