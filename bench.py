@@ -60,12 +60,17 @@ def latest_profile(pattern):
 def traffic_model(n_envs):
     """HBM bytes per launch of the dominant kernel as a function of the control steps in the launch, from the two latest
     committed PMC runs of that kernel at this batch size (separate FETCH_SIZE / WRITE_SIZE passes, calibrated on a
-    dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py): a 1-step launch and an S-step launch (S = 250)
+    dword-per-lane copy: tools/hbm_traffic.py + tools/hbm_traffic_report.py): two launch lengths of the rollout kernel (25 and 250
+    steps; before r03_v5: a 1-step launch of the step kernel and a 250-step launch)
     give  bytes(launch of k steps) = const + per_step * k.  The traffic is almost a per-launch constant (state in once,
     dirty lines out once; the per-step rows are overwritten in L2), so a per-env-step figure recorded at one launch length
     must not be scaled linearly to another.  PMC collection needs rocprofv3 around the process, so bench.py reports the
     model and names its sources; (None, None) if a file is missing."""
-    f1, fs = latest_profile("*hbm_traffic_%d.json" % n_envs), latest_profile("*hbm_traffic_rollout_%d.json" % n_envs)
+    fs = latest_profile("*hbm_traffic_rollout_%d.json" % n_envs)
+    f1 = latest_profile("*hbm_traffic_rollout25_%d.json" % n_envs)          # a second launch length of the SAME kernel, if recorded
+    same_kernel = bool(f1) and bool(fs) and os.path.basename(f1).split("_hbm_")[0] == os.path.basename(fs).split("_hbm_")[0]
+    if not same_kernel:
+        f1 = latest_profile("*hbm_traffic_%d.json" % n_envs)                # else the 1-step launch of the step kernel
     if not f1 or not fs:
         return None, None
     with open(f1) as fh:
@@ -81,8 +86,9 @@ def traffic_model(n_envs):
     info = {"bytes_per_launch_const": const, "bytes_per_step": per_step,
             "fitted_from": [{"file": os.path.relpath(f1, ROOT), "steps_per_launch": s1, "bytes_per_launch": b1},
                             {"file": os.path.relpath(fs, ROOT), "steps_per_launch": ss, "bytes_per_launch": bs}],
-            "note": "1-step launches are the step kernel, S-step launches the rollout kernel (same step_env code, state resident in "
-                    "LDS between the steps)"}
+            "note": ("two launch lengths of the rollout kernel" if same_kernel else
+                     "1-step launches are the step kernel, S-step launches the rollout kernel (same step_env code, state resident in "
+                     "LDS between the steps)")}
     return (lambda k: const + per_step * k), info
 
 

@@ -116,7 +116,7 @@ class StepJudge:
             self._branches(st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o)
         return dict(ok=ok, e_obs=e_obs, e_rew=e_rew, matched_e=matched_e, tol=tol_o, s=s_obs, category=category, near=near,
                     int_ok=int_ok, int_excused=int_excused, e_o32_o64=np.abs(b["obs"] - ref["obs"]).max(axis=1),
-                    e_hip_o64=np.abs(g_obs - ref["obs"]).max(axis=1),
+                    e_hip_o64=np.abs(g_obs - ref["obs"]).max(axis=1), tol_rew=tol_r, g_int=g_int, b_int=b_int, stable=stable,
                     oracle=b, next_state=so)
 
     def _branches(self, st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o):

@@ -117,8 +117,11 @@ def _judged_step(J, g, st, a):
     og, rg, dg, _ = g.step(a)
     raw = g._info.cpu().numpy()
     r = J.judge(st, a, og, rg, np.asarray(dg).astype(bool), g.get_state().cpu().numpy(), raw[:, 2], raw[:, 4])
-    assert r["ok"].all(), "env-steps outside their bound: %s (errors %s, bounds %s)" % (
-        np.nonzero(~r["ok"])[0][:8], r["matched_e"][~r["ok"]][:8], r["tol"][~r["ok"]][:8])
+    bad = ~r["ok"]
+    assert r["ok"].all(), ("env-steps outside their bound: %s (obs errors %s, bounds %s; reward errors %s, bounds %s; integers equal %s, "
+                           "near a threshold %s, probe stable %s; integers [n count elapsed ctr_lo ctr_hi flags done bad update] hip %s oracle %s)" % (
+        np.nonzero(bad)[0][:8], r["matched_e"][bad][:8], r["tol"][bad][:8], r["e_rew"][bad][:8], r["tol_rew"][bad][:8], r["int_ok"][bad][:8],
+        r["near"][bad][:8], r["stable"][bad][:8], r["g_int"][bad][:4].tolist(), r["b_int"][bad][:4].tolist()))
     return r, og, rg, dg
 
 

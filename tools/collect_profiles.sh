@@ -27,9 +27,18 @@ for N in 4096 32768; do
   python $R/tools/hbm_traffic_report.py /tmp/hb $N step > $O/${tag}_hbm_traffic_$N.json
   python $R/tools/hbm_traffic_report.py /tmp/hb $N rollout > $O/${tag}_hbm_traffic_rollout_$N.json
 done
+# a second launch length of the rollout kernel: bench.py fits bytes(launch of k steps) = const + per_step * k from the two
+rm -rf /tmp/hb25
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/hb25/$C -- python $R/tools/hbm_traffic.py 4096 25 > /dev/null 2>&1
+done
+python $R/tools/hbm_traffic_report.py /tmp/hb25 4096 rollout 25 > $O/${tag}_hbm_traffic_rollout25_4096.json
 python $R/tools/pmc_profile.py 4096 $O/${tag}_pmc_4096.json rollout > /dev/null
 python $R/tools/pmc_profile.py 4096 $O/${tag}_pmc_step_4096.json step > /dev/null
 python $R/tools/pmc_profile.py 32768 $O/${tag}_pmc_32768.json rollout > /dev/null
 python $R/tools/scaling_n.py > $O/${tag}_scaling_envs.txt
 python $R/tools/contact_cost.py > $O/${tag}_regimes.txt
+( cd $R && python bench.py --ppo --no-cpu-baseline ) > $O/${tag}_bench_ppo.json 2>/dev/null
+( cd $R && python bench.py --steps 20 --warmup 5 ) > $O/${tag}_bench_driver_shape.json 2>/dev/null
+( cd $R && python -c "import __graft_entry__ as g; g.smoke()" ) > $O/${tag}_smoke.log 2>&1
 ls -la $O | tail -20

@@ -1,7 +1,7 @@
 """Workload for the HBM-traffic PMC passes.  Run under rocprofv3 with ONE of --pmc FETCH_SIZE / --pmc WRITE_SIZE:
-   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/hbm_traffic.py [N]
+   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python tools/hbm_traffic.py [N [S]]
 Launches (a) the calibration copy (known bytes: n*4 read, n*4 written, dword per lane like the step kernel) and
-(b) 20 single-step launches (ss::step_kernel*) and 4 launches of 250 control steps each (ss::rollout_kernel*) at N envs.
+(b) 20 single-step launches (ss::step_kernel*) and 4 launches of S control steps each (ss::rollout_kernel*; S = argv[2], default 250) at N envs.
 tools/hbm_traffic_report.py turns the two counter CSVs into bytes per launch."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n_envs, seed=0, device="cuda:0")
 env.reset()
-STEPS_PER_LAUNCH = 250
+STEPS_PER_LAUNCH = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 env.rollout_random(20, 0, steps_per_launch=1)
 env.rollout_random(4 * STEPS_PER_LAUNCH, 20, steps_per_launch=STEPS_PER_LAUNCH)
 torch.cuda.synchronize()

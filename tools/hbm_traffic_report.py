@@ -1,12 +1,12 @@
-"""usage: hbm_traffic_report.py <dir with *counter_collection.csv from the FETCH_SIZE and WRITE_SIZE passes> N [step|rollout]
+"""usage: hbm_traffic_report.py <dir with *counter_collection.csv from the FETCH_SIZE and WRITE_SIZE passes> N [step|rollout [S]]
 Prints calibrated HBM bytes per launch of the single-step kernel (default) or of the multi-step rollout kernel
-(tools/hbm_traffic.py launches it with 250 control steps per launch).  FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3); both
+(tools/hbm_traffic.py launches it with S control steps per launch, default 250).  FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3); both
 are calibrated on the dword-per-lane copy kernel of known size (MI355X_MICROARCH.md 'HBM': other access widths than
 16 B/lane are uncalibrated -> calibrate on your own access pattern)."""
 import csv, glob, sys, collections, json
 d, n_envs = sys.argv[1], int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "step"
-steps_per_launch = 250 if which == "rollout" else 1
+steps_per_launch = (int(sys.argv[4]) if len(sys.argv) > 4 else 250) if which == "rollout" else 1
 pat = "rollout_kernel" if which == "rollout" else "step_kernel"
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
