@@ -340,8 +340,8 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
 // Global stores of a step's outputs and state rows.  -DSS_NT_STORES makes them non-temporal (`nt`) in the one-launch-per-step
 // kernels: nothing reads the rows again before the kernel ends, and a kernel boundary on this chip writes back whatever is dirty in
 // eight private L2s -- measured 0.0648 -> 0.0640 ms/step at 4096 envs (system-scope write-through stores: the same).  Off by
-// default: one of five full GPU-suite runs of that build had an integer mismatch on a single env-step that 3000 repetitions of
-// the same test did not reproduce and no run of the plain build has shown; not worth 1.2 % of the secondary figure.
+// default: measured late in round 3, next to a non-reproducible one-step mismatch that the hunt could not tie to anything
+// (DESIGN.md 7); the committed profiles are of the plain stores.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SS_NT_STORES)
 typedef float ss_v4f __attribute__((ext_vector_type(4)));
 template <bool NT, class T>
