@@ -1,20 +1,25 @@
-"""The device's dynamics against the INDEPENDENT numpy evaluation, with no C oracle in between (run with `pytest -m gpu`).
+"""The device's step() against the INDEPENDENT numpy evaluation, with no C oracle in between (run with `pytest -m gpu`).
 
 tests/test_oracle_contact.py pins the C oracle's contact stage to tests/np_contact.py (dense J H^-1 J^T from recursive
-Newton-Euler, impulse-space Gauss-Seidel), tests/test_oracle_dynamics.py pins its ABA to tests/np_dynamics.py, and the GPU
-parity tests compare the HIP kernel with the C oracle.  This file closes the triangle: one control step (4 substeps) of the
-HIP kernel from injected states against 4 numpy substeps from the same float32 inputs -- nothing of oracle/ is evaluated
-between the inputs and the comparison (the oracle only supplies the contact-rich input states).
+Newton-Euler, impulse-space Gauss-Seidel), tests/test_oracle_dynamics.py its ABA to tests/np_dynamics.py,
+tests/test_oracle_env_numpy.py its env logic to tests/np_env.py, and the GPU parity tests compare the HIP kernel with the C
+oracle.  This file closes the triangle: one control step of the HIP kernel from injected states against tests/np_env.py's
+control step (four numpy substeps + observation / reward / termination written from PHYSICS.md's text) on the same float32
+inputs -- nothing of oracle/ is evaluated between the inputs and the comparison (it only supplied the contact-rich input
+states).  Env-steps on which the target advances are skipped (stone re-draw: Philox, pinned bit-exactly elsewhere).
 
 Tolerance (fp32 kernel against an fp64 evaluation, PHYSICS.md's amplification of rounding on a pivoting foot included, see
-DESIGN.md section 3): joint angles / base pose within 2e-6 in the median and 5e-5 at worst (measured 1.6e-7 / 6.6e-6);
-generalised velocities (O(1..10) rad/s; the observation scales them by 0.1) within 1e-4 in the median, 1e-3 for 99 % of the
-env-steps and 5e-3 at worst (measured 1.7e-5 / 2.3e-4 / 4.0e-4); the contact flags of both feet equal except where a corner is
-within 1e-5 of a detection threshold in the numpy evaluation (measured: equal on all)."""
+DESIGN.md section 3): joint angles / base pose within 2e-6 in the median and 5e-5 at worst (measured 1.7e-7 / 6.6e-6);
+generalised velocities (O(1..10) rad/s) within 1e-4 in the median, 1e-3 for 99 % of the env-steps and 5e-3 at worst (measured
+1.7e-5 / 2.3e-4 / 4.0e-4); OBSERVATIONS within the north star's 1e-4 on every env-step (measured 4.0e-5 at worst, 1.8e-6 median)
+and REWARDS within 1e-3 (measured 8.2e-5) away from the reward's own discontinuities (posture / joint-limit / height thresholds
+within 1e-4 are skipped); done equal; the contact flags of both feet equal except where a corner is within 1e-5 of a detection
+threshold in the numpy evaluation (measured: equal on all)."""
 import numpy as np
 import pytest
 
 import np_contact as npc
+import np_env
 import oracle_lib as ol
 from test_oracle_contact import contact_states
 
@@ -76,35 +81,57 @@ def test_device_step_matches_independent_numpy(env_id, kind):
     rng = np.random.default_rng(17)
     states = np.array(contact_states(kind, rng)[:160], np.float64).astype(np.float32)     # what the device will hold
     states[:, ol.S_ELAPSED] = 0                                                              # no time limit in play
+    states[:, ol.S_COUNT] = 0
+    for e in range(0, states.shape[0], 3):                        # every third robot onto its target stone: first-touch bonus
+        terrain = states[e, ol.S_TERRAIN].reshape(20, 6)
+        k = int(states[e, ol.S_N])
+        states[e, 0:3] += terrain[k][:3] - terrain[0][:3]
     n = states.shape[0]
     acts = rng.uniform(-1.2, 1.2, (n, 21)).astype(np.float32)
     g = SteppingStoneVecEnv(env_id, n, seed=3, device="cuda:0", return_numpy=True)
     g.update_curriculum(5)
     g.reset()
     g.set_state(states)
-    _, _, done, _ = g.step(acts)
+    obs, rew, done, _ = g.step(acts)
     sg = g.get_state().cpu().numpy().astype(np.float64)
     g.close()
-    e_pose, e_vel, flags_ok, flags_near, used = [], [], 0, 0, 0
+    e_pose, e_vel, e_obs, e_rew, flags_ok, flags_near, used, ended, bonus = [], [], [], [], 0, 0, 0, 0, 0
     for e in range(n):
-        if done[e]:
-            continue                                           # the auto-reset replaced the state
-        ref, feet, margin = numpy_control_step(m, states[e], acts[e])
+        ref = np_env.control_step(m, states[e], acts[e])          # the whole step() in numpy fp64: dynamics + env logic
+        if ref["advance"]:
+            continue                                               # stone re-draw (Philox): pinned bit-exactly elsewhere
+        mg = ref["margins"]
+        if min(mg["height"], mg["low"]) > 1e-4:
+            assert bool(done[e]) == ref["done"], "env %d: done %s vs numpy %s" % (e, done[e], ref["done"])
+        if min(mg["pitch"], mg["roll"], mg["qn"], mg["height"]) > 1e-4:     # away from the reward's own discontinuities
+            e_rew.append(abs(float(rew[e]) - ref["rew"]))
+        bonus += ref["count"] == 1
+        if done[e] or ref["done"]:
+            ended += 1
+            continue                                               # the auto-reset replaced state and observation
         used += 1
+        _, _, margin = numpy_control_step(m, states[e], acts[e])
         pose = np.r_[0:7, 13:34]
         vel = np.r_[7:13, 34:55]
-        e_pose.append(np.abs(sg[e, pose] - ref[pose]).max())
-        e_vel.append(np.abs(sg[e, vel] - ref[vel]).max())
+        e_pose.append(np.abs(sg[e, pose] - ref["state55"][pose]).max())
+        e_vel.append(np.abs(sg[e, vel] - ref["state55"][vel]).max())
         gflags = int(sg[e, ol.S_FLAGS])
-        same = gflags == ((1 if feet[0] else 0) | (2 if feet[1] else 0))
+        same = gflags == ref["flags"]
         flags_ok += same
-        if not same:
+        if same:
+            e_obs.append(np.abs(obs[e].astype(np.float64) - ref["obs"]).max())
+            assert int(sg[e, ol.S_COUNT]) == ref["count"] or margin < 1e-5
+        else:
             flags_near += margin < 1e-5
-            assert margin < 1e-5, "env %d: contact flags %d vs %s with every corner %.1e from a threshold" % (e, gflags, feet, margin)
-    e_pose, e_vel = np.array(e_pose), np.array(e_vel)
-    print("%s: %d env-steps against numpy (no oracle): pose error median %.1e / 99 %% %.1e / max %.1e, velocity error median %.1e / 99 %% "
-          "%.1e / max %.1e; contact flags equal on %d, %d near a threshold" % (kind, used, np.median(e_pose), np.quantile(e_pose, .99), e_pose.max(),
-                                                                             np.median(e_vel), np.quantile(e_vel, .99), e_vel.max(), flags_ok, flags_near))
-    assert used >= 100
+            assert margin < 1e-5, "env %d: contact flags %d vs %s with every corner %.1e from a threshold" % (e, gflags, ref["flags"], margin)
+    e_pose, e_vel, e_obs, e_rew = np.array(e_pose), np.array(e_vel), np.array(e_obs), np.array(e_rew)
+    print("%s: %d continuing env-steps against numpy (no oracle), %d ended, %d with a first-touch bonus: pose error median %.1e / max %.1e, "
+          "velocity error median %.1e / 99 %% %.1e / max %.1e, observation error median %.1e / 99 %% %.1e / max %.1e, reward error median "
+          "%.1e / 99 %% %.1e / max %.1e; contact flags equal on %d, %d near a threshold" % (
+              kind, used, ended, bonus, np.median(e_pose), e_pose.max(), np.median(e_vel), np.quantile(e_vel, .99), e_vel.max(),
+              np.median(e_obs), np.quantile(e_obs, .99), e_obs.max(), np.median(e_rew), np.quantile(e_rew, .99), e_rew.max(), flags_ok, flags_near))
+    assert used >= 100 and bonus >= 10
     assert np.median(e_pose) < 2e-6 and e_pose.max() < 5e-5
     assert np.median(e_vel) < 1e-4 and np.quantile(e_vel, 0.99) < 1e-3 and e_vel.max() < 5e-3
+    assert np.median(e_obs) < 1e-5 and e_obs.max() < 1e-4       # the north star's per-step bound, against numpy (measured 4.0e-5)
+    assert np.median(e_rew) < 2e-5 and e_rew.max() < 1e-3       # (measured 8.2e-5; progress = 60 x a position error)
