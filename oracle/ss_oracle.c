@@ -11,8 +11,11 @@
  * reference does pin: call sites common/envs_utils.py:642-666 (step / auto-reset / hooks), playground/train.py:
  * 231-272 (update_terrain, create_temp_states -> (121,60), update_sample_prob), playground/enjoy.py:52-64
  * (terrain_info columns), common/render_utils.py:47-69 (joint order).  What IS pinned here: Philox4x32-10 against
- * the Random123 known-answer vectors, ABA against an independent CRBA+RNEA numpy solve and analytic cases
- * (tests/test_oracle_*.py).
+ * the Random123 known-answer vectors, ABA against an independent CRBA+RNEA numpy solve and analytic cases, the contact
+ * stage (detection, Delassus operator, rows, projected Gauss-Seidel, tree response, integration) and the env logic
+ * (observation, reward, termination, target logic) against independent fp64 numpy evaluations written from
+ * docs/PHYSICS.md (tests/test_oracle_*.py, tests/np_dynamics.py, np_contact.py, np_env.py).  Those pin this file to the
+ * written specification, not the specification to PyBullet.
  *
  * Style: deliberately naive dense 6x6 spatial algebra, array-of-struct, one env at a time -- it shares no code
  * with the HIP kernels.  Build twice: -DSSO_REAL=float (parity) and -DSSO_REAL=double (drift characterisation).
