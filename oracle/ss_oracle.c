@@ -13,8 +13,9 @@
  * (terrain_info columns), common/render_utils.py:47-69 (joint order).  What IS pinned here: Philox4x32-10 against
  * the Random123 known-answer vectors, ABA against an independent CRBA+RNEA numpy solve and analytic cases, the contact
  * stage (detection, Delassus operator, rows, projected Gauss-Seidel, tree response, integration) and the env logic
- * (observation, reward, termination, target logic) against independent fp64 numpy evaluations written from
- * docs/PHYSICS.md (tests/test_oracle_*.py, tests/np_dynamics.py, np_contact.py, np_env.py).  Those pin this file to the
+ * (observation, reward, termination, target logic) and the sampler / reset (stone draw, reset pose) against independent
+ * fp64 numpy evaluations written from docs/PHYSICS.md (tests/test_oracle_*.py, tests/np_dynamics.py, np_contact.py,
+ * np_env.py, np_terrain.py).  Those pin this file to the
  * written specification, not the specification to PyBullet.
  *
  * Style: deliberately naive dense 6x6 spatial algebra, array-of-struct, one env at a time -- it shares no code
