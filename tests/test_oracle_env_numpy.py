@@ -58,3 +58,46 @@ def test_control_step_outputs_match_independent_numpy(kind):
     assert used >= 60 and plain >= 30 and ended >= 5 and limit >= 5 and bonus >= 3
     # the oracle returns float32 observations / rewards from its fp64 evaluation: float32 rounding of O(1..30) values
     assert worst["obs"] < 1e-6 and worst["rew"] < 1e-5 and worst["state"] < 1e-10
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_create_temp_states_matches_independent_numpy(kind):
+    """PHYSICS.md 8: the current observation with the look-ahead stone n+1 re-placed at each of the 121 grid cells (same step
+    length, same tilts), rows in grid order i*11+j."""
+    import np_terrain as npt
+    m = npc.rounded_model(kind)
+    o = ol.OracleEnv(kind, 12, seed=4, prec="f64")
+    o.set_curriculum(5)
+    o.reset()
+    for rnd in range(2):                                         # robots set onto their target stone: two advances, drawn stones in play
+        st = o.get_state()
+        for e in range(12):
+            terrain = st[e, ol.S_TERRAIN].reshape(20, 6)
+            k = int(st[e, ol.S_N])
+            st[e, 0:2] = terrain[k][:2]
+            st[e, 2] += terrain[k][2] - terrain[k - 1][2]
+        o.set_state(st)
+        for t in range(3):
+            o.step(np.zeros((12, 21), np.float32))
+    st = o.get_state()
+    tmp = o.create_temp_states()
+    assert tmp.shape == (12, 121, 60)
+    worst, moved = 0.0, 0
+    for e in range(12):
+        n = int(st[e, ol.S_N])
+        if n >= 19:
+            continue
+        moved += n > 1
+        terrain = st[e, ol.S_TERRAIN].reshape(20, 6)
+        base = np_env.observation(m, st[e], int(st[e, ol.S_FLAGS]), n)
+        for i in range(11):
+            for j in range(11):
+                s2 = st[e].copy()
+                t2 = s2[ol.S_TERRAIN].reshape(20, 6)
+                phi, dr = terrain[n][3] + npt.YAW[i], st[e, ol.S_NNDR]
+                t2[n + 1][:3] = terrain[n][:3] + dr * np.array([np.cos(npt.PITCH[j]) * np.cos(phi), np.cos(npt.PITCH[j]) * np.sin(phi), np.sin(npt.PITCH[j])])
+                ref = np_env.observation(m, s2, int(st[e, ol.S_FLAGS]), n)
+                assert np.array_equal(ref[:55], base[:55])
+                worst = max(worst, np.abs(tmp[e, i * 11 + j].astype(np.float64) - ref).max())
+    print("%s: create_temp_states of 12 envs (%d beyond their first target): worst |obs| %.1e" % (kind, moved, worst))
+    assert moved >= 3 and worst < 1e-6
