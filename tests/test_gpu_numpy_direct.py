@@ -135,3 +135,50 @@ def test_device_step_matches_independent_numpy(env_id, kind):
     assert np.median(e_vel) < 1e-4 and np.quantile(e_vel, 0.99) < 1e-3 and e_vel.max() < 5e-3
     assert np.median(e_obs) < 1e-5 and e_obs.max() < 1e-4       # the north star's per-step bound, against numpy (measured 4.0e-5)
     assert np.median(e_rew) < 2e-5 and e_rew.max() < 1e-3       # (measured 8.2e-5; progress = 60 x a position error)
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_device_reset_and_stone_draw_match_independent_numpy(env_id, kind):
+    """PHYSICS.md 6 / 7 on the device against tests/np_terrain.py (its own Philox4x32-10), no oracle: the reset pose, and the stones
+    drawn on three real target advances per env with a peaked custom grid."""
+    import np_terrain as npt
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    m = npc.rounded_model(kind)
+    seed, n = 0x5EED12345, 40
+    g = SteppingStoneVecEnv(env_id, n, seed=seed, device="cuda:0", return_numpy=True)
+    g.update_curriculum(5)
+    prob = np.random.default_rng(0).random((11, 11)) ** 6
+    prob = prob / prob.sum()
+    g.update_sample_prob(prob)
+    prob = prob.astype(np.float32)
+    g.reset()
+    st = g.get_state().cpu().numpy().astype(np.float64)
+    for e in range(n):
+        assert np.abs(st[e, ol.S_Q] - npt.reset_joint_angles(m, seed, 0, e)).max() < 1e-6
+        assert int(st[e, ol.S_CTRLO]) + (int(st[e, ol.S_CTRHI]) << 16) == 6 and int(st[e, ol.S_N]) == 1
+    drawn = 0
+    for rnd in range(3):
+        st = g.get_state().cpu().numpy().astype(np.float64)
+        k = st[:, ol.S_N].astype(int)
+        for e in range(n):
+            terrain = st[e, ol.S_TERRAIN].reshape(20, 6)
+            st[e, 0:2] = terrain[k[e]][:2]
+            st[e, 2] += terrain[k[e]][2] - (terrain[k[e] - 1][2] if rnd else 0.0)
+        g.set_state(st.astype(np.float32))
+        before = g.get_state().cpu().numpy().astype(np.float64)
+        for t in range(3):
+            g.step(np.zeros((n, 21), np.float32))
+        after = g.get_state().cpu().numpy().astype(np.float64)
+        for e in range(n):
+            if int(after[e, ol.S_N]) != k[e] + 1 or k[e] + 2 > 19:
+                continue
+            ctr = int(before[e, ol.S_CTRLO]) + (int(before[e, ol.S_CTRHI]) << 16)
+            if int(after[e, ol.S_CTRLO]) + (int(after[e, ol.S_CTRHI]) << 16) != ctr + 1:
+                continue                                         # a reset in between consumed blocks as well
+            ta = after[e, ol.S_TERRAIN].reshape(20, 6)
+            ref, cell = npt.draw_stone(ta[k[e] + 1], prob, 5, npt.uniforms(seed, ctr, 0, e))
+            assert np.abs(ta[k[e] + 2] - ref).max() < 2e-6, (e, ta[k[e] + 2], ref, cell)
+            drawn += 1
+    g.close()
+    print("%s: reset poses of %d envs and %d drawn stones equal to the numpy evaluation (no oracle)" % (kind, n, drawn))
+    assert drawn >= 60
