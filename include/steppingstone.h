@@ -162,6 +162,10 @@ int ss_version(void);
  * ss_debug_phase_cycles: 16 per-phase shader-clock totals (zeros unless built with -DSS_PROFILE_PHASES). */
 int ss_debug_calib_copy(const float* in, float* out, uint64_t n, void* stream);
 int ss_debug_phase_cycles(ss_env* env, unsigned long long* out16, int reset);
+/* Self-check aid: the global id of env e becomes env_id_offset + (e & mask) (default mask: all ones), so that envs e and
+ * e + 2^k share their Philox streams; injected with the same state they must come out bit-equal from one launch
+ * (tests/test_gpu_first_launch.py, tests/host/first_launch_check.c). */
+int ss_debug_set_id_mask(ss_env* env, uint32_t mask);
 
 #ifdef __cplusplus
 }

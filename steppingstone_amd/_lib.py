@@ -19,7 +19,7 @@ SYMBOLS = [
     "ss_create_temp_states", "ss_get_mirror_indices", "ss_get_state", "ss_set_state", "ss_get_obs", "ss_num_envs",
     "ss_version", "ss_set_sample_prob_device", "ss_debug_calib_copy", "ss_debug_phase_cycles",
     "ss_peer_alloc", "ss_peer_free", "ss_peer_ipc_handle", "ss_peer_ipc_open", "ss_peer_ipc_close", "ss_peer_connect",
-    "ss_step_packed_peers", "ss_peer_wait", "ss_peer_error", "ss_rollout_random_packed",
+    "ss_step_packed_peers", "ss_peer_wait", "ss_peer_error", "ss_rollout_random_packed", "ss_debug_set_id_mask",
 ]
 
 
@@ -66,6 +66,7 @@ def load():
     lib.ss_peer_error.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.ss_debug_calib_copy.argtypes = [vp, vp, u64, vp]
     lib.ss_debug_phase_cycles.argtypes = [vp, vp, C.c_int]
+    lib.ss_debug_set_id_mask.argtypes = [vp, C.c_uint32]
     lib.ss_set_mirror.argtypes = [vp, i32]
     lib.ss_set_power.argtypes = [vp, f32]
     lib.ss_set_auto_reset.argtypes = [vp, i32]

@@ -182,6 +182,7 @@ int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t see
   P.seed_lo = (uint32_t)seed;
   P.seed_hi = (uint32_t)(seed >> 32);
   P.env_offset = (uint32_t)env_id_offset;
+  P.id_mask = 0xFFFFFFFFu;
   env->hk.curriculum = 0;
   env->hk.power = 1.0f;
   env->hk.auto_reset = 1;
@@ -496,6 +497,14 @@ int ss_debug_calib_copy(const float* in, float* out, uint64_t n, void* stream) {
   hipLaunchKernelGGL(ss::calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
                      (size_t)n);
   SS_HIP(hipGetLastError());
+  return SS_OK;
+}
+
+// Self-check aid (tests/test_gpu_first_launch.py): envs e and e' with (e & mask) == (e' & mask) share their global id, i.e. their
+// Philox streams (reset noise, stone draws, benchmark actions); given the same state they must produce the same bits in one launch.
+int ss_debug_set_id_mask(ss_env* env, uint32_t mask) {
+  if (!env) return fail(SS_ERR_INVALID, "null handle");
+  env->P.id_mask = mask;
   return SS_OK;
 }
 

@@ -109,6 +109,25 @@ struct Prof { int unused; };
 #define SS_PROF(i) ((void)0)
 #endif
 
+// Schedule fuzzing (-DSS_FUZZ_SCHED; test builds only, tools/sched_fuzz.py): every wavefront sleeps a pseudo-random time at the
+// start of each barrier window (and at the other hand-over points of a control step), so that the relative timing of the main
+// and the helper wavefronts differs from launch to launch and from window to window.  Nothing but the barriers may order the
+// hand-off region: the fuzzed build must produce the bits of the plain build.
+#if defined(SS_FUZZ_SCHED) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void ss_fuzz(uint32_t site) {
+  uint32_t h = (uint32_t)__builtin_amdgcn_s_memtime() ^ (site * 0x9E3779B9u);     // differs per wavefront, launch and visit
+  h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  h = __builtin_amdgcn_readfirstlane(h);
+  // one visit in four: up to 255 x 64 clocks (longer than the longest window); the others up to 15 x 64 clocks
+  const uint32_t n = ((h >> 8) & 3u) == 0u ? (h & 255u) : (h & 15u);
+#pragma unroll 1
+  for (uint32_t i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#define SS_FUZZ(site) ss_fuzz(site)
+#else
+#define SS_FUZZ(site) ((void)0)
+#endif
+
 // cos / sin of the joint angles on the helper wavefronts (and the joint torques ahead of them on the main one) from this many
 // helpers on.  Measured: with three helpers 0.0598 -> 0.0581 ms/step at 4096 envs; a single helper that also evaluates the 12
 // cos / sin is slower than leaving them on the main wavefront (16384 envs, rollout kernel: 0.0631 vs 0.0608 ms/step).
@@ -596,6 +615,7 @@ SSD void jacobian_rows(const DetectOut& det, const Lds& L, ssf2 (&rWp)[12][3], f
 template <class Model, int HELPERS, class Extra>
 __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&& extra) {
   __syncthreads();                                   // #0
+  SS_FUZZ(0x10u + helper);
   if constexpr (cs_offload(HELPERS)) {   // cos / sin of the 12 joint angles for everybody: helpers 1 and 2 take six each
     constexpr int kPer = HELPERS >= 3 ? 6 : NH;
     const int first = HELPERS >= 3 ? (helper - 1) * 6 : 0;
@@ -610,6 +630,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
       for (int k = 0; k < kPer; ++k) { L.hs(kHandCs + first + k) = c_[k]; L.hs(kHandCs + NH + first + k) = s_[k]; }
     }
     __syncthreads();                                 // #0b
+    SS_FUZZ(0x20u + helper);
   }
   float rowdir[12][3], rowB[4];       // helper 0: directions of the contact rows, Baumgarte terms
   if (helper == 0) {
@@ -676,6 +697,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
   }
   extra(helper);
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
+  SS_FUZZ(0x30u + helper);
   JointCache jin, jc;
   static_for<3, 8>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
@@ -690,6 +712,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     if (HELPERS == 1 || helper == c) operator_pair_a<Model, c>(jin, L, jc, oc[HELPERS == 1 ? c : 0]);
   });
   __syncthreads();                                   // #2: spine records and the base factor
+  SS_FUZZ(0x40u + helper);
   if (rows_offload(HELPERS) && helper == 0) {
 #pragma unroll
     for (int row = 0; row < 12; ++row)
@@ -722,6 +745,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     }
   });
   __syncthreads();                                   // #3: C, T and Lambda_own are ready
+  SS_FUZZ(0x50u + helper);
 }
 #endif
 
@@ -732,7 +756,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   constexpr float h = kH;
   JointCache jc;
 #if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (HELPERS > 0) __syncthreads();        // #0: the state of this substep is in LDS (helper 0: kinematics + detection)
+  if constexpr (HELPERS > 0) { __syncthreads(); SS_FUZZ(0x1Fu); }   // #0: the state of this substep is in LDS (helper 0: kinematics + detection)
 #endif
   SS_PROF(0);
   // LDS round trips (~100 cycles) are fully exposed with one wavefront per SIMD, and the compiler issues each
@@ -763,6 +787,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                   // #0b: cos / sin are in the hand-off region
+    SS_FUZZ(0x2Fu);
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -957,6 +982,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
         // operations only), and the helpers' part A would overlap nothing
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();               // #1
+        SS_FUZZ(0x3Fu);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
@@ -1040,6 +1066,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       for (int m = 0; m < 6; ++m) L.hs(kHandL0 + 15 + m) = jc.L0.di[m];
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                 // #2
+      SS_FUZZ(0x4Fu);
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
@@ -1319,6 +1346,7 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
     if (in_contact) rows_free();
 #if defined(__HIP_DEVICE_COMPILE__)
     __syncthreads();                 // #3: the helper wavefront(s) have written C, T and Lambda_own
+    SS_FUZZ(0x5Fu);
 #endif
     if (in_contact) solve();
   }

@@ -47,6 +47,7 @@ struct Params {
   int npad;              // padded to a multiple of 64
   uint32_t seed_lo, seed_hi;
   uint32_t env_offset;
+  uint32_t id_mask;      // global env id = env_offset + (e & id_mask): all ones, except under ss_debug_set_id_mask (duplicate-env self-check)
   unsigned long long* prof;   // 16 phase counters, tuning builds (-DSS_PROFILE_PHASES) only
 };
 
@@ -75,7 +76,7 @@ SSD void stone_normal(float phi, float xt, float yt, float n[3]) {
 }
 
 SSD void env_block(const Params& P, int e, uint32_t& ctr, uint32_t out[4]) {
-  philox4x32_10(ctr, 0u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, out);
+  philox4x32_10(ctr, 0u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, out);
   ctr += 1u;
 }
 
@@ -566,7 +567,7 @@ template <class Write>
 SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t tt, Write&& write) {
   uint32_t ra[6][4];
 #pragma unroll
-  for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, ra[b]);
+  for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, ra[b]);
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
     constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
@@ -651,6 +652,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   const int nsteps = ROLLOUT ? io.nsteps : 1;
 #pragma unroll 1
   for (int kstep = 0; kstep < nsteps; ++kstep) {
+  SS_FUZZ(0x60u);
   // clipped actions of this lane's joints (its own world) into LDS
   if constexpr (RANDOM_ACT) {
     bool drawn = false;
@@ -687,6 +689,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
 #endif
 #pragma unroll 1
   for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG power, fr, L);
+  SS_FUZZ(0x61u);
   SS_PROF(12);
   SS_MEMBAR();
   SS_OPAQUE(e);                                 // recompute every global address below instead of spilling 27 pointers
@@ -838,6 +841,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     }
   });
   // 11. output stage (emit_outputs): inline, or on helper 1 in the three-helper rollout kernel
+  SS_FUZZ(0x62u);
   if constexpr (ROLLOUT || kOffload) {
     // the LDS copy of the state is what comes next (the next step, helper 1's output stage): refresh what the env logic changed
     if (do_reset) {
@@ -929,6 +933,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
   __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
+  SS_FUZZ(0x70u + wave);
   if (wave == 0) {
     step_env<Model, RANDOM_ACT, HELPERS>(P, io, blockIdx.x * kWave + lane, lane, lds);
   } else {
@@ -948,6 +953,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
   __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
+  SS_FUZZ(0x70u + wave);
   if (wave == 0) {
     step_env<Model, true, HELPERS, true>(P, io, blockIdx.x * kWave + lane, lane, lds);
   } else {
@@ -961,6 +967,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
       for (int k = 0; k < SS_NUM_SUBSTEPS; ++k)
         helper_substep<Model, HELPERS>(wave - 1, L, [&](int helper) {
           if (k != 0) return;
+          SS_FUZZ(0x80u + helper);
           // the next control step's actions, while the main wavefront is in pass 1 / 2 of this step's first substep
           if (HELPERS > 1 && helper == HELPERS - 1 && kstep + 1 < io.nsteps)
             random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
@@ -969,6 +976,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
         });
     if constexpr (out_offload(HELPERS, true)) {
       __syncthreads();                 // the last step's results are in the hand-off region
+      SS_FUZZ(0x90u + wave);
       if (wave == 2) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, io.nsteps - 1, lds);
     }
   }
@@ -1142,7 +1150,7 @@ static __global__ void random_actions_kernel(Params P, uint64_t t, float* act) {
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
     uint32_t r[4];
-    philox4x32_10((uint32_t)(6u * (uint32_t)t + b), 1u, P.env_offset + (uint32_t)e, 0u, P.seed_lo, P.seed_hi, r);
+    philox4x32_10((uint32_t)(6u * (uint32_t)t + b), 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int j = b * 4 + i;

@@ -31,6 +31,11 @@ def _rebuild_parameter(data, requires_grad, hooks):
     return data
 
 
+_STORAGE_DTYPES = {"FloatStorage": "<f4", "DoubleStorage": "<f8", "HalfStorage": "<f2", "LongStorage": "<i8", "IntStorage": "<i4",
+                   "ShortStorage": "<i2", "CharStorage": "i1", "ByteStorage": "u1", "BoolStorage": "?"}
+_MAGIC = 0x1950A86A20F9469CFC6C          # torch/serialization.py MAGIC_NUMBER of the legacy (pre-zip) format
+
+
 class _U(pickle.Unpickler):
     def find_class(self, mod, name):
         if (mod, name) == ("collections", "OrderedDict"):
@@ -47,20 +52,34 @@ class _U(pickle.Unpickler):
         if pid[0] == "module":
             return pid[1]
         if pid[0] == "storage":
-            return ("storage", pid[2], pid[4])        # key, numel
+            stype = pid[1] if isinstance(pid[1], str) else getattr(pid[1], "__name__", str(pid[1]))
+            if stype not in _STORAGE_DTYPES:
+                raise pickle.UnpicklingError("unknown storage type %r" % (pid[1],))
+            self.storage_types[pid[2]] = stype
+            return ("storage", pid[2], pid[4], stype)        # key, numel, type
         raise pickle.UnpicklingError(pid)
 
 
 def read_legacy(path):
-    f = open(path, "rb")
-    for _ in range(3):
-        pickle.load(f)                                # magic, protocol, sys info
-    obj = _U(f).load()
-    keys = pickle.load(f)
-    storages = {}
-    for k in keys:
-        n = struct.unpack("<q", f.read(8))[0]
-        storages[k] = np.frombuffer(f.read(4 * n), dtype="<f4").copy()
+    """(module object of stubs, {storage key: 1-D numpy array in the storage's own dtype})."""
+    with open(path, "rb") as f:
+        magic = pickle.load(f)
+        if magic != _MAGIC:
+            raise ValueError("%s is not a legacy (pre-zip) torch.save file (magic %r)" % (path, magic))
+        pickle.load(f)                                # protocol version
+        pickle.load(f)                                # sys info
+        u = _U(f)
+        u.storage_types = {}
+        obj = u.load()
+        keys = pickle.load(f)
+        storages = {}
+        for k in keys:
+            n = struct.unpack("<q", f.read(8))[0]
+            dt = np.dtype(_STORAGE_DTYPES[u.storage_types.get(k, "FloatStorage")])
+            raw = f.read(dt.itemsize * n)
+            if len(raw) != dt.itemsize * n:
+                raise ValueError("%s: storage %s is truncated" % (path, k))
+            storages[k] = np.frombuffer(raw, dtype=dt).copy()
     return obj, storages
 
 
@@ -72,30 +91,39 @@ def tensors_of(obj, storages, prefix="", out=None):
             if isinstance(v, tuple) and v and v[0] == "tensor":
                 _, st, off, size, stride = v
                 flat = storages[st[1]]
-                out[prefix + k] = np.lib.stride_tricks.as_strided(flat[off:], size, [s * 4 for s in stride]).copy()
+                out[prefix + k] = np.lib.stride_tricks.as_strided(flat[off:], size, [s * flat.itemsize for s in stride]).copy()
     for k, m in (d.get("_modules") or {}).items():
         tensors_of(m, storages, prefix + k + ".", out)
     return out
 
 
-
-
 def load_reference_checkpoint(path, device="cpu"):
-    """ActorCritic (one critic) carrying the weights of a reference checkpoint: actor.fc1..fc5 / out, dist.logstd._bias ->
-    logstd, critic.{0,2,4,6,8} -> critics.0.*.  Raises KeyError if the file does not hold that architecture."""
+    """ActorCritic carrying the weights of a reference checkpoint: actor.fc1..fc5 / out, dist.logstd._bias -> logstd, and the value
+    networks: the current reference registers its ensemble as modules c0, c1, ... (common/controller.py:94-95; the shipped Mike
+    policy) -> critics.{i}.*, older files hold one module `critic` (the shipped Walker3D policies) -> critics.0.*.  The ensemble
+    size and the state / action dimensions are taken from the file.  Raises KeyError if the file does not hold that architecture."""
+    import re
     import torch
     from . import ppo
     obj, storages = read_legacy(path)
     w = tensors_of(obj, storages)
-    ac = ppo.ActorCritic(num_ensembles=1)
-    sd = {}
+    sd, ens = {}, set()
     for k, v in w.items():
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        m = re.match(r"c(\d+)\.(.*)", k)
         if k.startswith("actor."):
-            sd[k] = torch.from_numpy(v)
+            sd[k] = t
         elif k == "dist.logstd._bias":
-            sd["logstd"] = torch.from_numpy(v.reshape(-1))
+            sd["logstd"] = t.reshape(-1)
         elif k.startswith("critic."):
-            sd["critics.0." + k[len("critic."):]] = torch.from_numpy(v)
+            sd["critics.0." + k[len("critic."):]] = t
+            ens.add(0)
+        elif m:
+            sd["critics.%d.%s" % (int(m.group(1)), m.group(2))] = t
+            ens.add(int(m.group(1)))
+    if "actor.fc1.weight" not in sd or "logstd" not in sd or not ens or ens != set(range(len(ens))):
+        raise KeyError("not a SoftsignActor / critic checkpoint: %s holds %s" % (path, sorted(w)[:8]))
+    ac = ppo.ActorCritic(state_dim=sd["actor.fc1.weight"].shape[1], action_dim=sd["logstd"].numel(), num_ensembles=len(ens))
     missing = set(ac.state_dict()) - set(sd)
     if missing:
         raise KeyError("not a SoftsignActor / critic checkpoint: %s lacks %s" % (path, sorted(missing)))

@@ -80,7 +80,7 @@ int hh_step(int kind, int n, unsigned long long seed, int curriculum, const doub
   ss::Knobs K;
   K.prob = pr.data(); K.per_env_prob = 0; K.curriculum = curriculum; K.power = 1.f; K.auto_reset = 1;
   P.fstate = f.data(); P.istate = is.data(); P.terrain = terr.data(); P.knobs = &K;
-  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32); P.env_offset = 0; P.id_mask = 0xFFFFFFFFu;
   ss::StepIO io{act, obs, rew, done, info, 0, nullptr, 1, nullptr, 0, 0};
   for (int e = 0; e < n; ++e) ss::unpack_env(P, e, packed_in);
   const int waves = (2 * n + 63) / 64;

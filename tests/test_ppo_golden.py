@@ -4,6 +4,7 @@ backed env.  CPU only."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from steppingstone_amd import ppo
@@ -117,27 +118,63 @@ def test_adaptive_sampler_grid():
         envs.update_sample_prob(np.repeat(p[None], n, axis=0))      # what train.py:267-271 does
 
 
-def test_reference_checkpoint_loader():
-    """steppingstone_amd.legacy_checkpoint: the reference's shipped Walker3D policy (legacy torch.save of the pickled Policy
-    module) read with the restricted unpickler -- no reference code executed -- and mapped onto ActorCritic; the deterministic
-    action must equal a numpy forward pass over the raw arrays of the file (this container only: the file lives under
-    /root/reference)."""
+REF_MODELS = "/root/reference/playground/models/"
+
+
+@pytest.mark.parametrize("name,dims,critic_prefixes", [
+    ("mocca_envs:Walker3DStepperEnv-v0_latest.pt", (60, 21), ["critic."]),       # older layout: one module `critic`
+    ("mocca_envs:Walker3DStepperEnv-v0_best.pt", (60, 21), ["critic."]),
+    ("mocca_envs:Walker3DStepperEnv-v0_base.pt", (60, 21), ["critic."]),
+    ("mocca_envs:MikeStepperEnv-v0_latest.pt", (60, 21), ["c0."]),               # current layout: ensemble modules c0, c1, ... (controller.py:94-95)
+    ("CassieStepper-v1_base.pt", (51, 10), ["c0.", "c1."]),                       # train.py:37's default env: other dims, two critics
+])
+def test_reference_checkpoint_loader(name, dims, critic_prefixes):
+    """steppingstone_amd.legacy_checkpoint: EVERY policy the reference ships (legacy torch.save of the pickled Policy module) read
+    with the restricted unpickler -- no reference code executed -- and mapped onto ActorCritic; the deterministic action and every
+    ensemble member's value must equal a numpy forward pass over the raw arrays of the file (this container only: the files live
+    under /root/reference)."""
     import os
-    path = "/root/reference/playground/models/mocca_envs:Walker3DStepperEnv-v0_latest.pt"
+    path = REF_MODELS + name
     if not os.path.exists(path):
         pytest.skip("reference checkout not present")
     from steppingstone_amd import legacy_checkpoint as lc
     ac = lc.load_reference_checkpoint(path)
     obj, st = lc.read_legacy(path)
     w = lc.tensors_of(obj, st)
+    assert ac.actor.fc1.weight.shape[1] == dims[0] and ac.logstd.numel() == dims[1] and len(ac.critics) == len(critic_prefixes)
     rng = np.random.default_rng(0)
-    x = rng.normal(size=(5, 60)).astype(np.float32)
+    x = rng.normal(size=(5, dims[0])).astype(np.float32)
     h = x.astype(np.float64)
     for i, act in ((1, "softsign"), (2, "softsign"), (3, "softsign"), (4, "relu"), (5, "relu")):
         h = h @ w["actor.fc%d.weight" % i].T.astype(np.float64) + w["actor.fc%d.bias" % i]
         h = h / (1 + np.abs(h)) if act == "softsign" else np.maximum(h, 0)
     ref = np.tanh(h @ w["actor.out.weight"].T.astype(np.float64) + w["actor.out.bias"])
+    vals = []
+    for pre in critic_prefixes:
+        h = x.astype(np.float64)
+        for li in (0, 2, 4, 6):
+            h = np.maximum(h @ w["%s%d.weight" % (pre, li)].T.astype(np.float64) + w["%s%d.bias" % (pre, li)], 0)
+        vals.append(h @ w[pre + "8.weight"].T.astype(np.float64) + w[pre + "8.bias"])
     with torch.no_grad():
         v, a, _ = ac.act(torch.from_numpy(x), deterministic=True)
+        ve = ac.get_ensemble_values(torch.from_numpy(x))
     assert np.abs(a.numpy() - ref).max() < 1e-5
+    assert np.abs(ve.numpy() - np.concatenate(vals, axis=1)).max() < 1e-3 * max(1.0, np.abs(np.concatenate(vals, axis=1)).max())
     assert np.allclose(ac.logstd.detach().numpy(), w["dist.logstd._bias"].reshape(-1)) and v.shape == (5, 1)
+
+
+def test_legacy_reader_rejects_other_files(tmp_path):
+    """Not a legacy torch.save stream -> ValueError (the magic number is checked), a truncated one -> an error, never garbage."""
+    import os
+    from steppingstone_amd import legacy_checkpoint as lc
+    p = tmp_path / "x.pt"
+    torch.save({"a": torch.zeros(3)}, str(p))                       # the zip format
+    with pytest.raises(Exception):
+        lc.read_legacy(str(p))
+    src = REF_MODELS + "mocca_envs:MikeStepperEnv-v0_latest.pt"
+    if os.path.exists(src):
+        raw = open(src, "rb").read()
+        q = tmp_path / "cut.pt"
+        q.write_bytes(raw[: len(raw) - 1000])
+        with pytest.raises(Exception):
+            lc.read_legacy(str(q))
