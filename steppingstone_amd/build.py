@@ -67,36 +67,64 @@ def build_learner(force=False, verbose=False):
     return LEARNER_LIB
 
 
+FUZZ_LIB = os.path.join(LIBDIR, "libsteppingstone_fuzz.so")
+
+
+def _compile_lib(out, extra_flags, tag, verbose):
+    """Both translation units in parallel, then the link.  A compiler that does not know the optional -mllvm flag gets the plain
+    flags on a second pass; that pass keeps its diagnostics (a genuine compile error must be readable)."""
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src, with_optional, quiet):
+        obj = os.path.join(objdir, src.replace(".hip", tag + ".o"))
+        cmd = [hipcc()] + FLAGS + extra_flags + (OPTIONAL_FLAGS if with_optional else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return obj, subprocess.Popen(cmd, stderr=subprocess.DEVNULL if quiet else None)
+
+    for with_optional in (True, False):
+        jobs = [compile_one(src, with_optional and src not in NO_MAX_ILP, quiet=with_optional and not verbose) for src in SOURCES]
+        rcs = [p.wait() for _, p in jobs]
+        if all(rc == 0 for rc in rcs):
+            break
+        if not with_optional:
+            raise subprocess.CalledProcessError(max(rcs), "hipcc -c (diagnostics above)")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in jobs] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
+def _stale(lib):
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_fuzz(force=False, verbose=False):
+    """The -DSS_FUZZ_SCHED build of the same sources (lib/libsteppingstone_fuzz.so): every wavefront sleeps a pseudo-random time at the
+    start of each barrier window.  TEST BUILD -- tests/test_gpu_sched_fuzz.py requires its results to be bit-identical to the
+    product library's; nothing in the package loads it."""
+    if not force and not _stale(FUZZ_LIB):
+        return FUZZ_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    return _compile_lib(FUZZ_LIB, ["-DSS_FUZZ_SCHED"], "_fuzz", verbose)
+
+
 def build(force=False, verbose=False):
     build_learner(force, verbose)
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-
-    def compile_one(src, with_optional):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + (OPTIONAL_FLAGS if with_optional else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        return obj, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)
-
-    # the translation units compile in parallel; a compiler that does not know the optional -mllvm flag gets the plain flags
-    for with_optional in (True, False):
-        jobs = [compile_one(src, with_optional and src not in NO_MAX_ILP) for src in SOURCES]
-        rcs = [p.wait() for _, p in jobs]
-        if all(rc == 0 for rc in rcs):
-            break
-        if not with_optional:
-            raise subprocess.CalledProcessError(max(rcs), "hipcc -c")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _ in jobs] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile_lib(LIB, [], "", verbose)
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--fuzz" in sys.argv:
+        build_fuzz(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -99,7 +99,9 @@ inline dim3 grid64(const ss_env* env) { return dim3(env->P.npad / ss::kWave); }
 
 template <bool RANDOM>
 int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
-  const dim3 grid(env->P.npad / ss::kEnvsPerWave);     // two lanes per env: 32 envs per 64-lane wavefront
+  // two lanes per env: 32 envs per 64-lane wavefront.  ceil(n / 32) workgroups, NOT npad / 32: the arrays are padded to 64 envs, and
+  // for n mod 64 in 1..32 the padding used to launch one workgroup without a single valid env (see emit_outputs: nvalid).
+  const dim3 grid((env->P.n + ss::kEnvsPerWave - 1) / ss::kEnvsPerWave);
   SS_HIP(hipSetDevice(env->device));                   // the stream belongs to this device
   const int helpers = helpers_for(env, (int)grid.x);
   if (helpers == 3) {
@@ -124,7 +126,7 @@ int launch_step(ss_env* env, const ss::StepIO& io, hipStream_t st) {
 
 // io.nsteps control steps in one launch, actions from the benchmark Philox stream
 int launch_rollout(ss_env* env, const ss::StepIO& io, hipStream_t st) {
-  const dim3 grid(env->P.npad / ss::kEnvsPerWave);
+  const dim3 grid((env->P.n + ss::kEnvsPerWave - 1) / ss::kEnvsPerWave);
   SS_HIP(hipSetDevice(env->device));
   const int helpers = helpers_for(env, (int)grid.x);
   if (helpers == 3) {

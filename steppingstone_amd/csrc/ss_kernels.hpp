@@ -452,7 +452,11 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
   {
     SS_WAVE_SYNC();
     const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
-    const int nvalid = kEnvsPerWave < P.n - env0 ? kEnvsPerWave : P.n - env0;
+    // (never negative: a wavefront without a valid env -- not launched since round 4, ss_api.hip: grid = ceil(n / 32) -- would
+    // otherwise reach copy_block with nfl < 0, where `n4 << 2` rounds below nfl and lanes 0 and 1 stored two out-of-range LDS words
+    // into the reward / done slots of env n - 1's PACKED row: the schedule-dependent step of DESIGN.md 4.1b)
+    const int nleft = P.n - env0;
+    const int nvalid = nleft <= 0 ? 0 : (kEnvsPerWave < nleft ? kEnvsPerWave : nleft);
     // copy the staged block (nfl floats from the start of the LDS staging area) to dst: float4 when dst is 16-byte aligned
     auto copy_block = [&](float* dst, int nfl) {
       if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {

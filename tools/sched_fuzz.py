@@ -1,6 +1,6 @@
 """Schedule-fuzz fingerprint (run on the GPU box).
 
-    python tools/sched_fuzz.py [ENV_STEPS_PER_CONFIG]                       -> one line per configuration: a position-sensitive
+    python tools/sched_fuzz.py [ENV_STEPS_PER_CONFIG [TINY_STEPS]]                   -> one line per configuration: a position-sensitive
                                                                               checksum of EVERY step's packed [N,62] block
                                                                               (obs | rew | done), of every step's info words and
                                                                               of the final state
@@ -11,7 +11,7 @@
 
 Configurations: both robots x {three helpers, one helper, plain kernel} x {one launch per step with an action tensor (steps/launch=0 below), one launch per step with
 on-device actions, 32 steps per launch}, curriculum 5
-(stone draws, resets, target advances all occur), plus ragged tiny batches (1, 3, 33, 700 envs).  Two runs that print the same lines
+(stone draws, resets, target advances all occur), plus ragged tiny batches (1 ... 700 envs).  Two runs that print the same lines
 computed the same bits on every env-step.  tools/sched_fuzz.sh runs plain once and fuzzed three times and diffs."""
 import os
 import sys
@@ -23,7 +23,11 @@ import torch  # noqa: E402
 from steppingstone_amd.envs import SteppingStoneVecEnv  # noqa: E402
 
 TARGET = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+TINY_STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 CHUNK = 32
+# ragged tiny batches: n mod 64 in 1..32 is where the array padding (64 envs) exceeds the launch's last 32-env workgroup -- the odd
+# ones (1, 3, 5, 31, 65, 67) are the batch sizes whose packed row of env n - 1 was schedule-dependent until round 4
+TINY = (1, 3, 5, 31, 33, 65, 67, 700)
 
 
 class Sum:
@@ -92,10 +96,10 @@ if __name__ == "__main__":
                 print("%-22s n=%-6d helpers=%d steps/launch=%-3d steps=%-6d %s" % (env_id, n, helpers, per_launch, steps,
                                                                                   run(env_id, n, helpers, per_launch, steps)), flush=True)
                 total += steps * n
-        for n in (1, 3, 33, 700):
+        for n in TINY:
             for helpers in (3, 1, 0):
                 for per_launch in (0, 1, 7):
-                    steps = 2000
+                    steps = TINY_STEPS
                     print("%-22s n=%-6d helpers=%d steps/launch=%-3d steps=%-6d %s" % (env_id, n, helpers, per_launch, steps,
                                                                                       run(env_id, n, helpers, per_launch, steps)), flush=True)
                     total += steps * n
