@@ -163,7 +163,7 @@ class SteppingStoneVecEnv:
 
     closed = False
 
-    def __init__(self, env_id, num_envs, seed=0, device=None, env_id_offset=0, return_numpy=False, backend=None):
+    def __init__(self, env_id, num_envs, seed=0, device=None, env_id_offset=0, return_numpy=False, backend=None, log_dir=None):
         self.env_id = env_id
         self.kind = kind_of(env_id)
         self.num_envs = int(num_envs)
@@ -194,6 +194,11 @@ class SteppingStoneVecEnv:
                             "info": torch.zeros((n, INFO_WORDS), dtype=torch.int32).pin_memory(),
                             "event": torch.cuda.Event()}
         self._tstart = time.time()
+        # Monitor's files (common/envs_utils.py:36-38,172-194): <log_dir>/<rank>.monitor.csv per env, a row per finished episode
+        self._monitor = None
+        if log_dir is not None:
+            from .monitor_csv import MonitorFiles
+            self._monitor = MonitorFiles(log_dir, self.num_envs, env_id, first_rank=env_id_offset, t_start=self._tstart)
         self.yaw_samples = np.linspace(-20.0, 20.0, GRID) * DEG
         self.pitch_samples = np.linspace(-30.0, 30.0, GRID) * DEG
         self.yaw_sample_size = GRID
@@ -240,14 +245,18 @@ class SteppingStoneVecEnv:
             obs = out[:, :OBS_DIM].copy()                       # fresh arrays every step, like common/envs_utils.py:619
             rew = out[:, OBS_DIM].astype(np.float64)
             done = out[:, OBS_DIM + 1] > 0.5
-            return obs, rew, done, self._info_dicts(done, pb["info"].numpy())
+            self._info_host = pb["info"].numpy()
+            return obs, rew, done, self._info_dicts(done, self._info_host)
         self._pending = False
         if not self.return_numpy:
+            if self._monitor is not None:      # opt-in (log_dir): the episode rows need the finished envs on the host every step
+                self._info_dicts(self._done.cpu().numpy().astype(bool))
             return self._obs, self._rew, self._done.bool(), self._info_tensors()
         obs = self._obs.cpu().numpy()
         rew = self._rew.cpu().numpy().astype(np.float64)
         done = self._done.cpu().numpy().astype(bool)
-        return obs, rew, done, self._info_dicts(done)
+        self._info_host = self._info.cpu().numpy()
+        return obs, rew, done, self._info_dicts(done, self._info_host)
 
     def step(self, actions):
         self.step_async(actions)
@@ -283,6 +292,8 @@ class SteppingStoneVecEnv:
     def close(self):
         if self.closed:
             return
+        if self._monitor is not None:
+            self._monitor.close()
         self.backend.close()
         self.closed = True
 
@@ -401,6 +412,8 @@ class SteppingStoneVecEnv:
             bad, reached = raw[idx, 2].tolist(), raw[idx, 3].tolist()
             for k, i in enumerate(idx.tolist()):
                 d = {"episode": {"r": round(rets[k], 6), "l": lens[k], "t": now}, "steps_reached": reached[k]}
+                if self._monitor is not None:
+                    self._monitor.write_row(i, d["episode"])
                 if bad[k]:
                     d["bad_transition"] = True
                 infos[i] = d
@@ -455,7 +468,7 @@ class SteppingStoneEnv:
 
     def step(self, action):
         obs, rew, done, infos = self.vec.step(np.asarray(action, np.float32).reshape(1, ACT_DIM))
-        raw = self.vec._info.cpu().numpy()[0]
+        raw = self.vec._info_host[0]          # the step's info words, already on the host (no second copy)
         self.update_terrain = bool(raw[4])
         self.robot.feet_contact[:] = obs[0, 48:50]
         info = dict(infos[0])
@@ -501,8 +514,8 @@ def make_env(env_id, render=False, seed=0, device=None):
 
 def make_vec_envs(env_id, seed, num_processes, log_dir=None, device=None, return_numpy=True, env_id_offset=0):
     """Counterpart of common/envs_utils.py:48-56: `num_processes` environments with seeds seed+rank.  The reference
-    forks one process per env; here they are lanes of one kernel on `device`.  (log_dir is accepted for signature
-    compatibility; episode returns arrive in info["episode"] exactly as Monitor delivers them.)"""
+    forks one process per env; here they are lanes of one kernel on `device`.  log_dir: as in make_env_fns (:36-38), env `rank`
+    logs its episodes to <log_dir>/<rank>.monitor.csv (steppingstone_amd/monitor_csv.py); None: no files, as in the reference."""
     assert num_processes > 1
     return SteppingStoneVecEnv(env_id, num_processes, seed=seed, device=device, env_id_offset=env_id_offset,
-                               return_numpy=return_numpy)
+                               return_numpy=return_numpy, log_dir=log_dir)
