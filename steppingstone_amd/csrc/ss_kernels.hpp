@@ -924,6 +924,38 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
 }
 
 #ifndef SS_HOST_HARNESS
+// Experiment (-DSS_CODE_PREFETCH=bytes, off by default): the helper wavefronts, idle until the main wavefront has loaded
+// the state, read the kernel's own code (from the entry point on) as data, so that the main wavefront's instruction fetches of a
+// launch's first control step find the lines in L2 instead of HBM / MALL (a kernel boundary invalidates the L2s of all eight XCDs).
+#if defined(SS_CODE_PREFETCH)
+__device__ __forceinline__ void prefetch_code(unsigned long long entry_pc, int helper, int nhelpers, int lane, uint32_t* sink) {
+  const uint4* p = reinterpret_cast<const uint4*>(entry_pc & ~63ull);
+  uint32_t acc = 0;
+#pragma unroll 4
+  for (int i = helper * kWave + lane; i < (SS_CODE_PREFETCH) / 16; i += nhelpers * kWave) { const uint4 v = p[i]; acc ^= v.x ^ v.w; }
+  if (acc == 0x9E3779B9u && sink) *sink = acc;       // (keeps the loads alive; practically never taken)
+}
+#define SS_PREFETCH_ENTRY() const unsigned long long entry_pc_ = __builtin_amdgcn_s_getpc()
+#define SS_PREFETCH(helper, n, lane) prefetch_code(entry_pc_, helper, n, lane, reinterpret_cast<uint32_t*>(P.prof))
+#else
+#define SS_PREFETCH_ENTRY() ((void)0)
+#define SS_PREFETCH(helper, n, lane) ((void)0)
+#endif
+// Layout experiment (-DSS_ENTRY_PAD=n / -DSS_HELPER_PAD=n: n `s_nop`s, 4 bytes each, executed once per launch at the kernel's entry /
+// at the head of the helper wavefronts' branch): the helped kernels are 77-85 KB of code against a 64 KB instruction cache shared by
+// two CUs, so where the main and the helper wavefronts' hot code falls in the cache is worth a few per cent.
+#define SS_STR2(x) #x
+#define SS_STR(x) SS_STR2(x)
+#if defined(SS_ENTRY_PAD) && defined(__HIP_DEVICE_COMPILE__)
+#define SS_PAD_ENTRY() asm volatile(".rept " SS_STR(SS_ENTRY_PAD) "\n s_nop 0\n .endr")
+#else
+#define SS_PAD_ENTRY() ((void)0)
+#endif
+#if defined(SS_HELPER_PAD) && defined(__HIP_DEVICE_COMPILE__)
+#define SS_PAD_HELPER() asm volatile(".rept " SS_STR(SS_HELPER_PAD) "\n s_nop 0\n .endr")
+#else
+#define SS_PAD_HELPER() ((void)0)
+#endif
 template <class Model, bool RANDOM_ACT>
 __global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
   __shared__ float4 lds4[kLdsSlots * kWave];
@@ -934,6 +966,8 @@ __global__ __launch_bounds__(kWave, 1) void step_kernel(Params P, StepIO io) {
 // helper_substep).  Worth it only while the batch leaves SIMDs idle (4096 envs occupy 128 of 1024).
 template <class Model, bool RANDOM_ACT, int HELPERS>
 __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(Params P, StepIO io) {
+  SS_PREFETCH_ENTRY();
+  SS_PAD_ENTRY();
   __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
@@ -941,6 +975,8 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
   if (wave == 0) {
     step_env<Model, RANDOM_ACT, HELPERS>(P, io, blockIdx.x * kWave + lane, lane, lds);
   } else {
+    SS_PREFETCH(wave - 1, HELPERS, lane);
+    SS_PAD_HELPER();
     const Lds L{lds, lane};
 #pragma unroll 1
     for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L, [](int) {});
@@ -954,6 +990,8 @@ __global__ __launch_bounds__(kWave, 1) void rollout_kernel(Params P, StepIO io) 
 }
 template <class Model, int HELPERS>
 __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helped(Params P, StepIO io) {
+  SS_PREFETCH_ENTRY();
+  SS_PAD_ENTRY();
   __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
@@ -961,6 +999,8 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
   if (wave == 0) {
     step_env<Model, true, HELPERS, true>(P, io, blockIdx.x * kWave + lane, lane, lds);
   } else {
+    SS_PREFETCH(wave - 1, HELPERS, lane);
+    SS_PAD_HELPER();
     const Lds L{lds, lane};
     const int lane_global = blockIdx.x * kWave + lane, side = lane_global & 1;
     const int e = min(lane_global >> 1, P.n - 1);
