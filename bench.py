@@ -249,6 +249,44 @@ def launch_shape(W, K, spl, ms_per_step, prewarm=0):
             "rocprofv3_stats_average_ms_expected": ms_per_step * sum(every) / max(len(every), 1)}
 
 
+PHASE = {"name": "start"}          # what the rank is doing, for the watchdog's error line
+
+
+def start_watchdog(args, rank, world):
+    """A multi-GPU run that hangs (a rank that died, a collective that never completes, an xGMI link down) must say so: after
+    --watchdog seconds every rank still running prints ONE JSON line {"error": ..., "phase": ..., "rank": ...} and leaves with exit
+    code 3, so the driver's SCALE file holds a reason instead of a timeout."""
+    import threading
+    limit = args.watchdog if args.watchdog >= 0 else (900.0 if (world > 1 or args.gpus > 1) else 0.0)
+    if limit <= 0:
+        return None
+
+    def fire():
+        line = json.dumps({"error": "watchdog: rank %d of %d still in phase '%s' after %.0f s -- a rank died or a collective hangs"
+                                    % (rank, world, PHASE["name"], limit), "rank": rank, "world_size": world, "phase": PHASE["name"],
+                           "metric": "env-steps/sec (batched random-action rollout)", "value": None, "n_gpus": world})
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+        os._exit(3)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def device_identity(torch, dist, dev, use_dist, world):
+    """PCI bus id and name of every rank's GPU (all-gathered): the line itself shows that N ranks sat on N different devices."""
+    p = torch.cuda.get_device_properties(dev)
+    mine = "%s %s" % (getattr(p, "pci_bus_id", "?") if not hasattr(p, "pci_domain_id") else
+                      "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id), p.name)
+    if not use_dist:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +308,9 @@ def main():
                          "envs per GPU, 32-step rollouts, actor/critic on PyTorch-ROCm), frames/s; --updates U")
     ap.add_argument("--updates", type=int, default=10, help="--ppo: number of PPO updates (<= 10 keeps the run under two minutes)")
     ap.add_argument("--dry-launch", action="store_true", help="start the N ranks, report RANK / WORLD_SIZE, exit (no GPU needed)")
+    ap.add_argument("--watchdog", type=float, default=-1.0,
+                    help="seconds after which a rank that has not finished prints a JSON error line and exits with code 3 instead of "
+                         "hanging in a collective (default: 900 at N > 1, off at N = 1; 0 = off)")
     args = ap.parse_args()
 
     # more hardware queues than HIP's default 4, so that RCCL's stream never shares one with the launch stream
@@ -280,6 +321,7 @@ def main():
     if rc is not None:
         raise SystemExit(rc)
     rank, local_rank, world = launch.rank_info()
+    watchdog = start_watchdog(args, rank, world)
     if args.dry_launch:
         # one write per line: the ranks share the launcher's stdout, and print() sends the text and the newline separately
         sys.stdout.write(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
@@ -308,6 +350,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    PHASE["name"] = "process group up"
+    devices = device_identity(torch, dist, dev, use_dist, world)
     n_local = args.envs_per_gpu
     if args.ppo:
         ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local)
@@ -354,8 +398,11 @@ def main():
     # milliseconds of load, and a short run (the driver has used --steps 20 --warmup 5) would otherwise time the ramp: 72.8 instead
     # of 82 M env-steps/s.  Collective-free steps on the local shard (the envs simply are 256 steps further along).
     PREWARM = 256
+    PHASE["name"] = "clock-ramp launch + first barrier"
     local.rollout_random(PREWARM, t0=1 << 20, steps_per_launch=PREWARM)
     sync()
+    PHASE["name"] = "warm-up / timed rollout (kernels + %s)" % ("RCCL all-gather" if gather else "no exchange")
+
     def reduce_max(x):
         if not use_dist:
             return x
@@ -382,6 +429,7 @@ def main():
     elapsed_min, elapsed_max = samples[order[0]][0], samples[order[-1]][0]
     # self-proof of the exchange, straight after the headline run: every rank checksums its own block and each peer's block
     # as received, the checksums are compared across ranks (ShardedVecEnv.verify_last_exchange)
+    PHASE["name"] = "exchange verification / side rows"
     gather_verified = None
     if use_dist and gather:
         try:
@@ -510,6 +558,7 @@ def main():
             out["policy_in_the_loop"] = {"value": pil.get("value", total_envs / (pil["ms_per_step"] * 1e-3)), "unit": "env-steps/s",
                                          "ms_per_step": pil["ms_per_step"],
                                          "what": "one kernel launch%s per control step" % (" + one RCCL all-gather of [N/G,62]" if gather else "")}
+        out["devices"] = devices
         if use_dist:
             out["gather_verified"] = gather_verified
             out["rccl_ranks"] = dist.get_world_size()
@@ -534,9 +583,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.write(json.dumps(out) + "\n")          # one write: nothing can land inside the line
         sys.stdout.flush()
+    PHASE["name"] = "final barrier"
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):

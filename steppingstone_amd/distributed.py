@@ -92,6 +92,12 @@ class ShardedVecEnv:
                                    "gathered rows of that step are stale; use the RCCL exchange (peer_gather=False) or remove the "
                                    "rank skew" % n)
 
+    def check_exchange(self, force=True):
+        """Raise if the peer-store exchange lost a step (a wait timed out).  A consumer calls this at the end of every rollout, before
+        it trains on the gathered rows (ppo.collect does; ADVICE r3: the internal every-32-steps poll is not aligned with rollouts
+        of another length).  No-op with the RCCL exchange, whose collectives cannot deliver stale rows silently."""
+        self._check_peer(force=force)
+
     # -- self-proof of the exchange
     def verify_last_exchange(self):
         """Collective.  Checks that the buffers of the LAST benchmark exchange (rollout_random / rollout_random_chunked with

@@ -345,6 +345,8 @@ def collect(envs, ac, roll, num_steps, ep_returns=None, ep_stats=None, ring=None
         elif ep_returns is not None and bool(done.any()):
             ep_returns.append(info["ep_ret"][done].clone())
         roll.insert(obs, action, logp, value, rew.unsqueeze(1), mask, bad_mask)
+    if hasattr(envs, "check_exchange") and not torch.cuda.is_current_stream_capturing():
+        envs.check_exchange()          # a multi-GPU exchange that lost a step must not be trained on (ShardedVecEnv, peer stores)
 
 
 class GraphedCollector:

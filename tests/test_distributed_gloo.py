@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo, one process per 'GPU', each rank owning a contiguous block of envs (oracle-
-backed test double), per-step all-gather of the packed [obs|rew|done] block.  The gathered result must equal a
-single-process run over all envs (global env ids key the RNG, so sharding is invisible).  CPU only."""
+"""N>1 path on CPU: gloo at world sizes 2 AND 8 (BASELINE configs[3] / [4] run 8 ranks), one process per 'GPU',
+each rank owning a contiguous block of envs (oracle-backed test double), per-step all-gather of the packed [obs|rew|done] block.
+The gathered result must equal a single-process run over all envs (global env ids key the RNG, so sharding is invisible: the
+partition arithmetic and the RNG invariance at G = 8, not only G = 2).  CPU only."""
 import os
 import sys
 
@@ -11,10 +12,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_LOCAL, WORLD, STEPS = 6, 2, 12
+N_LOCAL, STEPS = 6, 12
 
 
-def _worker(rank, port, ret):
+def _worker(rank, port, ret, WORLD):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -51,12 +52,13 @@ def _worker(rank, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_equals_single_process():
+@pytest.mark.parametrize("WORLD", [2, 8])
+def test_sharding_equals_single_process(WORLD):
     import oracle_lib as ol
-    port = 29500 + os.getpid() % 2000
+    port = 29500 + (os.getpid() + 17 * WORLD) % 2000
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(port, ret), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(port, ret, WORLD), nprocs=WORLD, join=True)
         res = {k: v for k, v in ret.items()}
     o = ol.OracleEnv("walker3d", N_LOCAL * WORLD, seed=5)
     ref = [o.reset()]

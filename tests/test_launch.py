@@ -51,3 +51,24 @@ def test_rank_count_mismatch_is_an_error():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], cwd=ROOT, env=e,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "launcher started 3 ranks" in (out.stderr + out.stdout)
+
+
+def test_bench_watchdog_prints_a_json_error_line_instead_of_hanging():
+    """bench.py's watchdog: a rank still running after --watchdog seconds prints ONE JSON line naming its phase and
+    exits with code 3 -- so that a hung collective at N > 1 leaves a reason in the driver's SCALE file, not a timeout."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time, types; sys.path.insert(0, %r); import bench\n"
+            "bench.PHASE['name'] = 'timed rollout (test)'\n"
+            "bench.start_watchdog(types.SimpleNamespace(watchdog=0.5, gpus=8), 3, 8)\n"
+            "time.sleep(30)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["rank"] == 3 and line["world_size"] == 8 and "timed rollout (test)" in line["error"] and line["value"] is None
+    # default: on at N > 1 (900 s), off at N = 1
+    import bench, types
+    assert bench.start_watchdog(types.SimpleNamespace(watchdog=-1.0, gpus=1), 0, 1) is None
+    t = bench.start_watchdog(types.SimpleNamespace(watchdog=-1.0, gpus=8), 0, 8)
+    assert t is not None and t.interval == 900.0
+    t.cancel()
