@@ -108,7 +108,7 @@ class PPO:
 
     def __init__(self, ac, clip_param=0.2, ppo_epoch=10, mini_batch_size=1024, value_loss_coef=1.0, entropy_coef=0.0,
                  lr=3e-4, eps=1e-5, max_grad_norm=2.0, use_clipped_value_loss=False, mirror_indices=None,
-                 use_graph=False):
+                 use_graph=False, graph_collectives=None, force_collective=False):
         self.ac = ac
         self.clip_param, self.ppo_epoch, self.mini_batch_size = clip_param, ppo_epoch, mini_batch_size
         self.value_loss_coef, self.entropy_coef, self.max_grad_norm = value_loss_coef, entropy_coef, max_grad_norm
@@ -125,11 +125,20 @@ class PPO:
         else:
             self.optimizer = torch.optim.Adam(ac.parameters(), lr=lr, eps=eps)
         self._graph, self._warm, self._static = None, 0, None
+        # Data-parallel learner (configs[4], one process per GPU): the minibatch step contains ONE RCCL all-reduce of the flat
+        # gradient.  graph_collectives (default: env SS_GRAPH_COLLECTIVES, "1" = on): capture that step -- collective included -- in
+        # a hipGraph as on one rank (RCCL supports stream capture; torch's ProcessGroupNCCL joins its stream to the capturing one).
+        # The capture is attempted once, after three eager warm-up steps (communicator set up); if it raises, the step stays eager
+        # and says so.  force_collective: issue the all-reduce at world size 1 too (how a one-GPU box tests the captured collective).
+        import os
+        self.graph_collectives = (os.environ.get("SS_GRAPH_COLLECTIVES", "1") == "1") if graph_collectives is None else bool(graph_collectives)
+        self.force_collective = bool(force_collective)
+        self.graph_fallback = None          # the exception text if a capture was attempted and abandoned
 
     def _allreduce_grads(self):
         """Data-parallel learner: one RCCL all-reduce of the flattened gradient per minibatch (no-op on one rank)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not self.force_collective):
             return
         grads = [p.grad for p in self.ac.parameters() if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -163,7 +172,11 @@ class PPO:
     # -- hipGraph path ------------------------------------------------------------------------------------------------
     def _graph_ok(self):
         import torch.distributed as dist
-        return self.use_graph and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if not self.use_graph or self.graph_fallback is not None:
+            return False
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective)
+        # several ranks: only a backend whose collectives run on a stream can be captured (RCCL; gloo's are host calls)
+        return (not multi) or (self.graph_collectives and dist.get_backend() == "nccl")
 
     def _gathered_step(self, data, idx):
         return self.step_minibatch(*(t[idx] for t in data))
@@ -189,9 +202,16 @@ class PPO:
                 return torch.stack(out)
             self.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._gathered_step(sdata, sidx)
-                sout.copy_(torch.stack(out))
+            try:
+                with torch.cuda.graph(g):
+                    out = self._gathered_step(sdata, sidx)
+                    sout.copy_(torch.stack(out))
+            except Exception as exc:          # (a collective that cannot be captured in this stack: stay eager, loudly)
+                self.graph_fallback = repr(exc)[:300]
+                import warnings
+                warnings.warn("PPO minibatch step: hipGraph capture abandoned, running eagerly (%s)" % self.graph_fallback)
+                torch.cuda.synchronize()
+                return torch.stack(self._gathered_step(data, idx))
             self._graph = g
         sidx.copy_(idx)
         self._graph.replay()
@@ -345,7 +365,8 @@ def collect(envs, ac, roll, num_steps, ep_returns=None, ep_stats=None, ring=None
         elif ep_returns is not None and bool(done.any()):
             ep_returns.append(info["ep_ret"][done].clone())
         roll.insert(obs, action, logp, value, rew.unsqueeze(1), mask, bad_mask)
-    if hasattr(envs, "check_exchange") and not torch.cuda.is_current_stream_capturing():
+    capturing = roll.obs.is_cuda and torch.cuda.is_current_stream_capturing()
+    if hasattr(envs, "check_exchange") and not capturing:
         envs.check_exchange()          # a multi-GPU exchange that lost a step must not be trained on (ShardedVecEnv, peer stores)
 
 
@@ -478,8 +499,12 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
+    # hipGraphs: the rollout (policy + env step + storage writes) on one rank; the minibatch step on one rank AND, with RCCL as the
+    # transport, at several ranks -- its single all-reduce is captured with it (PPO.graph_collectives; falls back to eager by itself)
+    graph_update = use_graph
     if use_graph == "auto":
         use_graph = dev.type == "cuda" and not multi
+        graph_update = dev.type == "cuda" and (not multi or dist.get_backend() == "nccl")
     torch.manual_seed(seed)
     ac = ActorCritic(num_ensembles=num_ensembles).to(dev)
     if multi:
@@ -504,7 +529,7 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
                 raise
             print("steppingstone_amd.ppo.train: fused learner unavailable (%s); using the torch learner" % exc)
     if agent is None:
-        agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=use_graph)
+        agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=graph_update)
     roll = Rollouts(num_steps, n, dev)
     ring = EpisodeRing(n, dev)
     any_logger = logger is not None
