@@ -11,7 +11,10 @@ Every env-step is bounded -- none passes on an allowance:
                step instead of granted)
   post-step state (round 4: what the NEXT step starts from, not only what the policy sees): base position, quaternion and joint
                angles <= max(1e-4, 8 s_pose); base twist and joint rates <= max(1e-3, 8 s_vel) (rates enter the observation as 0.1 q')
-  ceilings:    no bound may exceed 5e-3 (observation, pose), 5e-2 (velocities, reward), however ill-conditioned the step
+  loose bounds: an env-step whose bound exceeds 5e-3 (observation, pose) or 5e-2 (velocities, reward) is counted (`loose`); the tests
+               assert that such steps stay below 0.1 % of the env-steps (measured on 327 680 env-steps: 0.01 %, the states where a
+               body spins up before the episode ends).  A hard cap instead would fail the CPU's own fp32 build on those steps
+               (round 4 tried it: 26 "failures" of 327 680, every one of them a capped bound, errors inside 8 s)
 
 where s is the MEASURED first-order sensitivity of that very env-step in the fp64 build of the oracle: each of the 55
 dynamic state inputs (base pose / twist, q, qd) is perturbed by 8 ulp (relative 8 * 2^-23, floor 1e-3 absolute scale), one
@@ -42,7 +45,8 @@ import oracle_lib as ol
 
 OBS_TOL, REW_TOL, NEAR_TOL = 1e-4, 1e-4, 1e-5
 POSE_TOL, VEL_TOL = 1e-4, 1e-3              # post-step state: pos 3 + quat 4 + q 21 | base twist 6 + qd 21
-OBS_CEIL, POSE_CEIL, VEL_CEIL, REW_CEIL = 5e-3, 5e-3, 5e-2, 5e-2      # absolute ceilings of the sensitivity-scaled bounds
+OBS_CEIL, POSE_CEIL, VEL_CEIL, REW_CEIL = 5e-3, 5e-3, 5e-2, 5e-2      # a bound above these marks the env-step `loose` (counted, asserted rare)
+LOOSE_MAX_FRACTION = 1e-3
 POSE_COLS = list(range(0, 7)) + list(range(13, 34))
 VEL_COLS = list(range(7, 13)) + list(range(34, 55))
 ULPS, SENS_FACTOR = 8.0, 8.0
@@ -118,10 +122,10 @@ class StepJudge:
         d32 = np.abs(so[:, :NDYN].astype(np.float64) - ref["state"])
         s_pose = np.maximum(self.s_pose, d32[:, POSE_COLS].max(axis=1))
         s_vel = np.maximum(self.s_vel, d32[:, VEL_COLS].max(axis=1))
-        tol_o = np.minimum(np.maximum(OBS_TOL, SENS_FACTOR * s_obs), OBS_CEIL)
-        tol_r = np.minimum(np.maximum(REW_TOL, SENS_FACTOR * s_rew), REW_CEIL)
-        tol_p = np.minimum(np.maximum(POSE_TOL, SENS_FACTOR * s_pose), POSE_CEIL)
-        tol_v = np.minimum(np.maximum(VEL_TOL, SENS_FACTOR * s_vel), VEL_CEIL)
+        tol_o = np.maximum(OBS_TOL, SENS_FACTOR * s_obs)
+        tol_r = np.maximum(REW_TOL, SENS_FACTOR * s_rew)
+        tol_p = np.maximum(POSE_TOL, SENS_FACTOR * s_pose)
+        tol_v = np.maximum(VEL_TOL, SENS_FACTOR * s_vel)
         e_obs = np.abs(g_obs - b["obs"]).max(axis=1)
         e_rew = np.abs(g_rew - b["rew"])
         g_dyn = np.asarray(g_state)[:, :NDYN].astype(np.float64)
@@ -141,7 +145,8 @@ class StepJudge:
         return dict(ok=ok, e_obs=e_obs, e_rew=e_rew, matched_e=matched_e, tol=tol_o, s=s_obs, category=category, near=near,
                     int_ok=int_ok, int_excused=int_excused, e_o32_o64=np.abs(b["obs"] - ref["obs"]).max(axis=1),
                     e_hip_o64=np.abs(g_obs - ref["obs"]).max(axis=1), tol_rew=tol_r, g_int=g_int, b_int=b_int, stable=stable,
-                    e_pose=e_pose, e_vel=e_vel, tol_pose=tol_p, tol_vel=tol_v, oracle=b, next_state=so)
+                    e_pose=e_pose, e_vel=e_vel, tol_pose=tol_p, tol_vel=tol_v, oracle=b, next_state=so,
+                    loose=(tol_o > OBS_CEIL) | (tol_r > REW_CEIL) | (tol_p > POSE_CEIL) | (tol_v > VEL_CEIL))
 
     def _branches(self, st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o, g_dyn, e_pose, e_vel,
                   tol_r, tol_p, tol_v):
@@ -224,8 +229,8 @@ class StepJudge:
                 ea = np.abs(g_obs[e] - ra["obs"][e]).max()
                 er = abs(g_rew[e] - ra["rew"][e])
                 da = np.abs(g_dyn[e] - ra_state[e, :NDYN])
-                lim_o, lim_r = min(max(OBS_TOL, SENS_FACTOR * s_o[e]), OBS_CEIL), min(max(REW_TOL, SENS_FACTOR * s_r[e]), REW_CEIL)
-                lim_p, lim_v = min(max(POSE_TOL, SENS_FACTOR * s_p[e]), POSE_CEIL), min(max(VEL_TOL, SENS_FACTOR * s_v[e]), VEL_CEIL)
+                lim_o, lim_r = max(OBS_TOL, SENS_FACTOR * s_o[e]), max(REW_TOL, SENS_FACTOR * s_r[e])
+                lim_p, lim_v = max(POSE_TOL, SENS_FACTOR * s_p[e]), max(VEL_TOL, SENS_FACTOR * s_v[e])
                 ok[e] = bool(ea <= lim_o and er <= lim_r and da[POSE_COLS].max() <= lim_p and da[VEL_COLS].max() <= lim_v)
                 matched_e[e] = ea
                 tol_o[e] = lim_o
@@ -238,15 +243,15 @@ class StepJudge:
 def summarize(results):
     """Concatenate the per-step dicts of judge() and return (arrays, text)."""
     keys = ("ok", "e_obs", "e_rew", "matched_e", "tol", "s", "category", "near", "int_ok", "int_excused", "e_o32_o64", "e_hip_o64",
-            "tol_rew", "e_pose", "e_vel", "tol_pose", "tol_vel")
+            "tol_rew", "e_pose", "e_vel", "tol_pose", "tol_vel", "loose")
     r = {k: np.concatenate([x[k] for x in results]) for k in keys}
     cat = r["category"]
     plain = cat == 0
     txt = ("%d env-steps: %d plain = %.0f %% held to 1e-4 (max |obs| err %.2e), %d sensitive (max err / bound %.2f), %d matched another "
            "branch, %d another branch + sensitive; reward max err / bound %.2f, pose %.2f, velocities %.2f; integer mismatches excused by an "
-           "unstable probe: %d; failures: %d" % (
+           "unstable probe: %d; loose bounds: %d; failures: %d" % (
                cat.size, plain.sum(), 100.0 * plain.mean(), r["matched_e"][plain].max() if plain.any() else 0.0, (cat == 1).sum(),
                (r["matched_e"] / r["tol"])[cat == 1].max() if (cat == 1).any() else 0.0, (cat == 2).sum(), (cat == 3).sum(),
                (r["e_rew"] / r["tol_rew"])[cat < 2].max() if (cat < 2).any() else 0.0, (r["e_pose"] / r["tol_pose"])[cat < 2].max() if (cat < 2).any() else 0.0,
-               (r["e_vel"] / r["tol_vel"])[cat < 2].max() if (cat < 2).any() else 0.0, r["int_excused"].sum(), (~r["ok"]).sum()))
+               (r["e_vel"] / r["tol_vel"])[cat < 2].max() if (cat < 2).any() else 0.0, r["int_excused"].sum(), r["loose"].sum(), (~r["ok"]).sum()))
     return r, txt

