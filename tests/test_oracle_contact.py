@@ -207,7 +207,7 @@ def test_parity_rule_accepts_the_oracle_and_rejects_injected_errors():
             r3[e] += 0.1
             assert not J.judge(st, a, og, r3, dg, sg, ig["bad_transition"], ig["update_terrain"])["ok"][e]
             caught += 1
-        assert r["loose"].sum() <= 1
+        assert r["loose"].mean() <= 0.05
         assert (r["e_pose"] == 0).all() and (r["e_vel"] == 0).all()
         st = r["next_state"]
     assert caught >= 10
