@@ -601,10 +601,15 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
     from steppingstone_amd import ppo
     from steppingstone_amd.envs import SteppingStoneVecEnv
     U, T, MB = max(5, args.updates), 32, 1024
+    # "minibatch 1024 kept or scaled -- state the choice".  Both, torch learner: row A keeps the reference's minibatch of
+    # 1024 (playground/train.py:62; 128 minibatches per epoch of this rank's 131 072-frame rollout), row B keeps the reference's NUMBER
+    # of minibatches per epoch instead (train.py:63: 40000 // 1024 = 39; the nearest divisor of the rollout is 32 -> minibatch 4096).
+    MB_SCALED = max(MB, (T * n_local) // 32)
     rows = {}
-    for learner in ("torch", "fused"):
+    for key, learner, mb in (("torch", "torch", MB), ("torch_scaled", "torch", MB_SCALED), ("fused", "fused", MB)):
         if learner == "fused" and world > 1 and os.environ.get("SS_BENCH_TEST_TRANSPORT"):
             continue
+        PHASE["name"] = "ppo row %s (minibatch %d)" % (key, mb)
         envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n_local, seed=8, device=dev, env_id_offset=rank * n_local, return_numpy=False)
         stamps = []
 
@@ -616,17 +621,18 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
             if use_dist:
                 dist.barrier()
             t0 = time.perf_counter()
-            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=MB, use_curriculum=True, log=log, learner=learner)
+            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=mb, use_curriculum=True, log=log, learner=learner)
             torch.cuda.synchronize(dev)
             if use_dist:
                 dist.barrier()
             t1 = time.perf_counter()
             steady = (stamps[-1][1] - stamps[2][1]) / (stamps[-1][0] - stamps[2][0])
-            rows[learner] = {"value": steady, "unit": "frames/s", "whole_run_frames_per_s": stamps[-1][1] / (t1 - t0),
-                             "updates": U, "steady_state_updates": U - 3, "ms_per_update": 1e3 * (stamps[-1][0] - stamps[2][0]) / (U - 3),
-                             "mean_episode_return_first_last": [stamps[0][2], stamps[-1][2]], "curriculum_level_end": stamps[-1][3]}
+            rows[key] = {"value": steady, "unit": "frames/s", "whole_run_frames_per_s": stamps[-1][1] / (t1 - t0), "mini_batch_size": mb,
+                         "minibatches_per_epoch": (T * n_local) // mb,
+                         "updates": U, "steady_state_updates": U - 3, "ms_per_update": 1e3 * (stamps[-1][0] - stamps[2][0]) / (U - 3),
+                         "mean_episode_return_first_last": [stamps[0][2], stamps[-1][2]], "curriculum_level_end": stamps[-1][3]}
         except Exception as exc:
-            rows[learner] = {"value": None, "error": repr(exc)[:300]}
+            rows[key] = {"value": None, "error": repr(exc)[:300]}
         envs.close()
     if rank == 0:
         main = rows["torch"]
@@ -635,11 +641,14 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "MikeStepperEnv-v0, %d envs per MI355X, fixed-order curriculum on, PPO: %d-step rollouts, 10 epochs, "
                                       "minibatch %d, actor / critic (SoftsignActor + critic) on PyTorch-ROCm, hipGraph replay of rollout and "
-                                      "minibatch step at one rank, eager + gradient all-reduce at several" % (n_local, T, MB),
+                                      "minibatch step at one rank; at several ranks the rollout is eager and the minibatch step a hipGraph "
+                                      "with its RCCL all-reduce captured" % (n_local, T, MB),
                           "envs_total": n_local * world, "learner": "torch", "a_step_is": "one PPO update = %d frames" % (T * n_local * world),
                           "parallelism": "data-parallel x%d" % world},
-               "learner_torch": main, "learner_fused_side_row": rows.get("fused"),
-               "note": "random-init weights, synthetic rollouts of the env itself; the value is the torch-learner row"}
+               "learner_torch": main, "learner_torch_scaled_minibatch": rows.get("torch_scaled"), "learner_fused_side_row": rows.get("fused"),
+               "minibatch_choice": "value = row A: the reference's minibatch 1024 kept (train.py:62); learner_torch_scaled_minibatch = row B: the "
+                                   "reference's ~39 minibatches per epoch kept instead (train.py:63), i.e. minibatch %d" % MB_SCALED,
+               "note": "random-init weights, synthetic rollouts of the env itself; the value is the torch-learner row A"}
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 
