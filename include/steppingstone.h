@@ -34,7 +34,8 @@ extern "C" {
 #define SS_NUM_STONES 20
 #define SS_STATE_DIM 186  /* packed per-env state of ss_get_state / ss_set_state */
 #define SS_INFO_WORDS 6    /* 32-bit words of ss_info */
-#define SS_ABI_VERSION 3   /* ss_version(): 2 -> 3 added ss_info.ep_ret_lo and state word 185 (round 3) */
+#define SS_ABI_VERSION 4   /* ss_version(): 2 -> 3 added ss_info.ep_ret_lo and state word 185 (round 3); 3 -> 4 (round 4) changed a
+                            * MEANING, no layout: actions and observations carry POLICY coordinates, see "Joint conventions" */
 #define SS_MAX_EPISODE_STEPS 1000
 
 typedef enum { SS_WALKER3D = 0, SS_MIKE = 1 } ss_kind;   /* ids: README.md:27,31 of the reference */
@@ -69,7 +70,14 @@ int ss_create(ss_env** out, int kind, int32_t num_envs, int device, uint64_t see
 void ss_destroy(ss_env* env);                                   /* env.close(), envs_utils.py:667-676 */
 const char* ss_last_error(void);
 
-/* ShmemVecEnv.reset (envs_utils.py:542-548): obs [num_envs, 60] f32 row-major, device pointer. */
+/* Joint conventions.  Joint / action order: common/render_utils.py:47-69 (abdomen z,y,x; right hip x,z,y, knee, ankle; left ...;
+ * right shoulder x,z,y, elbow; left ...).  POLICY coordinates -- act[j], obs[6+j] (normalised angle), obs[27+j] (0.1 * rate):
+ * about the +axis of the link frame for the spine and the right limbs and about the MIRRORED axis for the left limbs' x / z
+ * joints (docs/PHYSICS.md 2, sigma = model.POLICY_SIGN), so that ss_get_mirror_indices swaps the limbs without negating them:
+ * the convention the reference's shipped actors were trained in (playground/models/ *.pt are mirror-equivariant under exactly
+ * these lists, tests/test_shipped_policy_layout.py).  ss_get_state / ss_set_state keep every angle about the +axis.
+ *
+ * ShmemVecEnv.reset (envs_utils.py:542-548): obs [num_envs, 60] f32 row-major, device pointer. */
 int ss_reset(ss_env* env, float* obs, void* stream);
 
 /* ShmemVecEnv.step_async + step_wait + worker auto-reset (envs_utils.py:550-558, 646-649).
@@ -138,7 +146,9 @@ int ss_set_auto_reset(ss_env* env, int32_t on);
 int ss_create_temp_states(ss_env* env, float* out, void* stream);
 
 /* env.unwrapped.get_mirror_indices() (train.py:160; consumed by get_mirror_function, envs_utils.py:687-694).
- * buf receives the 6 index lists back to back, lens[6] their lengths; buf must hold 2*(60+21) int32. */
+ * buf receives the 6 index lists back to back, lens[6] their lengths; buf must hold 2*(60+21) int32.
+ * Lists (policy coordinates): negated obs {vy, roll, abdomen z / x angle and rate, sin(dtheta) d and x_tilt of both targets},
+ * negated act {abdomen z, x}; right <-> left: the 9 limb joints (angle, rate, action) and the two contact flags. */
 int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens);
 
 /* Full-state injection / extraction for parity tests and terrain_info (enjoy.py:60-64).  DEVICE pointers,
@@ -154,7 +164,8 @@ int ss_get_obs(ss_env* env, float* obs, void* stream);
 
 int32_t ss_num_envs(const ss_env* env);
 /* SS_ABI_VERSION of the library.  A binding must check it at load time (steppingstone_amd/_lib.py does): version 2 inserted
- * steps_per_launch into ss_rollout_random's argument list, version 3 grew ss_info to 6 words and the packed state to 186. */
+ * steps_per_launch into ss_rollout_random's argument list, version 3 grew ss_info to 6 words and the packed state to 186,
+ * version 4 changed the sign convention of the left limbs' x / z joints in actions and observations (same layouts). */
 int ss_version(void);
 
 /* Measurement aids (tools/hbm_traffic.py, tools/phase_profile.py); not part of the env protocol.

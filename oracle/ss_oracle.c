@@ -687,8 +687,9 @@ static void write_obs(const sso_model* M, const env_state* s, float* o) {
   f[4] = roll; f[5] = pitch;
   for (int j = 0; j < NJ; ++j) {
     real mid = (real)0.5 * (M->lo[j] + M->hi[j]);
-    f[6 + j] = 2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j]);
-    f[27 + j] = (real)0.1 * s->qd[j];
+    /* policy coordinates (PHYSICS.md 2): sigma_j * (angle, rate about the +axis) */
+    f[6 + j] = SSO_POLICY_SIGN[j] * (2 * (s->q[j] - mid) / (M->hi[j] - M->lo[j]));
+    f[27 + j] = SSO_POLICY_SIGN[j] * ((real)0.1 * s->qd[j]);
   }
   f[48] = (s->flags & 1) ? 1 : 0;
   f[49] = (s->flags & 2) ? 1 : 0;
@@ -745,7 +746,7 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
   real a[NJ], tau[NJ];
   for (int j = 0; j < NJ; ++j) {
     a[j] = r_clamp((real)act[j], -1, 1);
-    tau[j] = E->power * M->torque[j] * a[j];
+    tau[j] = E->power * M->torque[j] * (SSO_POLICY_SIGN[j] * a[j]);   /* action in policy coordinates (PHYSICS.md 2) */
   }
   foot_report fr;
   warm_state ws;

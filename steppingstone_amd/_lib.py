@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("STEPPINGSTONE_LIB") or os.path.join(PKG, "lib", "libs
 
 OBS_DIM, ACT_DIM, GRID, NCELL, NUM_STONES, STATE_DIM, MAX_EPISODE_STEPS = 60, 21, 11, 121, 20, 186, 1000
 INFO_WORDS = 6            # ss_info: ep_ret, ep_len, bad_transition, steps_reached, update_terrain, ep_ret_lo
-ABI_VERSION = 3           # include/steppingstone.h SS_ABI_VERSION
+ABI_VERSION = 4           # include/steppingstone.h SS_ABI_VERSION
 WALKER3D, MIKE = 0, 1
 
 SYMBOLS = [

@@ -468,9 +468,12 @@ int ss_create_temp_states(ss_env* env, float* out, void* stream) {
 int ss_get_mirror_indices(int kind, int32_t* buf, int32_t* lens) {
   if (!buf || !lens) return fail(SS_ERR_INVALID, "null argument");
   (void)kind;   // both robots share the topology
-  static const int neg_j[] = {0, 2, 3, 4, 8, 9, 13, 14, 17, 18};
-  static const int right_j[] = {3, 4, 5, 6, 7, 13, 14, 15, 16};
-  static const int left_j[] = {8, 9, 10, 11, 12, 17, 18, 19, 20};
+  // In POLICY coordinates (docs/PHYSICS.md 2, ss::kPolicySign): the left limbs' x / z joints are measured about the mirrored
+  // axis, so a mirror swaps the limbs without negating them and only the spine's z / x joints negate in place -- the lists
+  // the reference's shipped actors are equivariant under (tools/checkpoint_layout_probe.py).  Generated from model.py.
+  const auto& neg_j = ss::kMirrorNegate;
+  const auto& right_j = ss::kMirrorRight;
+  const auto& left_j = ss::kMirrorLeft;
   std::vector<int32_t> neg_obs = {2, 4}, right_obs, left_obs, neg_act, right_act, left_act;
   for (int j : neg_j) neg_obs.push_back(6 + j);
   for (int j : neg_j) neg_obs.push_back(27 + j);

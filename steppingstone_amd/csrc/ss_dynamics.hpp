@@ -76,6 +76,13 @@ static_assert(S_END <= (kLdsSlots - kSlotsA) * 4, "LDS scalar region overflow");
 constexpr int kHalf[NH] = {0, 1, 2, 3, 4, 5, 6, 7, 13, 14, 15, 16};
 // joints whose angle changes sign under the y-mirror (rotation about x or z)
 constexpr bool mirror_flips(int j) { return kAxis[j] != 1; }
+// Policy coordinates (PHYSICS.md 2, kPolicySign): actions and observations measure the LEFT limbs' x / z joints about the
+// mirrored axis.  The left lane's mirrored world holds exactly that value for its limbs, so
+//   action (policy) -> lane world: only the spine's z / x joints change sign in the left lane;
+//   lane's TRUE-world angle -> observation: the left limbs' x / z joints change sign.
+// (tools/gen_model_tables.py asserts kPolicySign is -1 exactly on the left limbs' x / z joints.)
+__host__ __device__ constexpr float action_lane_sign(int jr, float m) { return (jr < 3 && mirror_flips(jr)) ? m : 1.f; }
+__host__ __device__ constexpr float policy_lane_sign(int jr, int side) { return (jr >= 3 && mirror_flips(jr) && side) ? -1.f : 1.f; }
 // highest-index child of body b inside the half-tree; -1 for leaves
 constexpr int first_child_half(int b) {
   int r = -1;

@@ -193,8 +193,9 @@ SSD void write_obs(const Dyn& s, float z_init, int flags, const Cache& c, float*
     constexpr int j = decltype(Jc)::value;
     constexpr float mid = 0.5f * (Model::lo[j] + Model::hi[j]);
     constexpr float span = Model::hi[j] - Model::lo[j];
-    obs[6 + j] = clip5(2.f * (s.q[j] - mid) / span);
-    obs[27 + j] = clip5(0.1f * s.qd[j]);
+    constexpr float ps = (float)kPolicySign[j];       // policy coordinates, PHYSICS.md 2 (negations are exact: same bits as emit_outputs)
+    obs[6 + j] = clip5(2.f * (ps * s.q[j] - ps * mid) / span);
+    obs[27 + j] = clip5(0.1f * (ps * s.qd[j]));
   });
   obs[48] = (flags & 1) ? 1.f : 0.f;
   obs[49] = (flags & 2) ? 1.f : 0.f;
@@ -398,14 +399,16 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
       constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
       const int gj = side ? jl : jr;
       if (jr >= 3 || side == 0) {
-        // normalisation with the TRUE joint's range: a mirrored x/z joint has range (-hi, -lo)
+        // The observation carries POLICY coordinates (PHYSICS.md 2: kPolicySign = -1 for the left limbs' x / z joints,
+        // i.e. the angle about the mirrored axis) -- the left lane's own mirrored-world value, normalised with the RIGHT
+        // twin's range (a left x / z joint's true range is (-hi, -lo)).  The state arrays keep angles about the +axis.
         constexpr float midr = 0.5f * (Model::lo[jr] + Model::hi[jr]);
         constexpr float span = Model::hi[jr] - Model::lo[jr];
-        const float mid = (side && mirror_flips(jr)) ? -midr : midr;
+        const float ps = policy_lane_sign(jr, side);
         gst<!ROLLOUT>(&Fo[(F_Q + gj) * np], o.qt[k]);
         gst<!ROLLOUT>(&Fo[(F_QD + gj) * np], o.qdt[k]);
-        SS_OBS(6 + gj) = clip5(2.f * (o.qt[k] - mid) / span);
-        SS_OBS(27 + gj) = clip5(0.1f * o.qdt[k]);
+        SS_OBS(6 + gj) = clip5(2.f * (ps * o.qt[k] - midr) / span);
+        SS_OBS(27 + gj) = clip5(0.1f * (ps * o.qdt[k]));
       }
     });
     if (side == 0) {
@@ -575,7 +578,7 @@ SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
     constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
-    const float sg = mirror_flips(jr) ? m : 1.f;
+    const float sg = action_lane_sign(jr, m);
     const uint32_t bits = side ? ra[jl / 4][jl % 4] : ra[jr / 4][jr % 4];
     write(k, sg * (2.f * u01(bits) - 1.f));
   });
@@ -674,7 +677,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   } else {
     static_for<0, NH>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value, jr = kHalf[k];
-      const float sg = mirror_flips(jr) ? m : 1.f;
+      const float sg = action_lane_sign(jr, m);
       const float x = ain[k];
       float a = fminf(fmaxf(x, -1.f), 1.f);
       a = (x != x) ? x : a;      // a NaN action is not clipped away (fmaxf would): it ends the episode, PHYSICS.md 4.8

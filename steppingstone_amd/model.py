@@ -46,9 +46,21 @@ AXIS = [2, 1, 0,
 RIGHT_FOOT_BODY = 8    # child of right_ankle (joint 7)
 LEFT_FOOT_BODY = 13    # child of left_ankle  (joint 12)
 
-# joints whose sign flips under a left/right mirror (rotations about x or z), and the
-# right/left pairs that swap; the spine's z and x joints negate in place.
-MIRROR_NEGATE_JOINTS = [0, 2, 3, 4, 8, 9, 13, 14, 17, 18]
+# POLICY-FACING joint coordinates (docs/PHYSICS.md section 2): what the action and the observation carry is
+# sigma_j * (torque, angle, rate about the +axis of the link frame).  sigma = -1 for the LEFT limbs' x and z joints: the
+# reference's env measures them about the mirrored axis, so that a left/right mirror of the policy's view swaps the
+# limbs WITHOUT negating them.  Evidence held by the reference: the shipped actors (playground/models/*.pt, trained
+# with common/envs_utils.py:687-740 on the env's own get_mirror_indices()) are mirror-equivariant to 0.06-0.08 under
+# exactly these lists and to 0.36-0.45 (random: 0.43-0.54) with the left x / z joints negated
+# (tools/checkpoint_layout_probe.py, profiles/r04_checkpoint_layout_*.txt).  The dynamics (state, oracle, kernels)
+# keep angles about the +axis; sigma is applied where actions enter and observations leave.
+POLICY_SIGN = [1, 1, 1,
+               1, 1, 1, 1, 1,
+               -1, -1, 1, 1, 1,
+               1, 1, 1, 1,
+               -1, -1, 1, 1]
+# get_mirror_indices() in policy coordinates: the spine's z and x joints negate in place, the limbs swap.
+MIRROR_NEGATE_JOINTS = [0, 2]
 MIRROR_RIGHT_JOINTS = [3, 4, 5, 6, 7, 13, 14, 15, 16]
 MIRROR_LEFT_JOINTS = [8, 9, 10, 11, 12, 17, 18, 19, 20]
 

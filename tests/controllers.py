@@ -21,12 +21,13 @@ def balance_controller(kind):
     rng = np.asarray(m["range"], np.float64)
     lo, hi, q0 = rng[:, 0], rng[:, 1], np.asarray(m["q0"], np.float64)
     mid, span = 0.5 * (lo + hi), hi - lo
+    sigma = np.asarray(model.POLICY_SIGN, np.float64)
     kp, kd, ap, av, hp, hv, kr, kv, ar, lean = GAINS[kind]
 
     def act(obs):
         o = np.asarray(obs, np.float64)
-        q = mid + o[:, 6:27] * span / 2          # un-normalise (obs = 2 (q - mid) / span)
-        qd = o[:, 27:48] * 10.0                  # obs = 0.1 qd
+        q = mid + sigma * o[:, 6:27] * span / 2  # un-normalise (obs = sigma 2 (q - mid) / span, policy coordinates: PHYSICS.md 2)
+        qd = sigma * o[:, 27:48] * 10.0          # obs = sigma 0.1 qd
         roll, pitch, vx, vy = o[:, 4], o[:, 5], o[:, 1], o[:, 2]
         a = kp * (q0[None, :] - q) - kd * qd
         for j in (7, 12):                        # ankle y
@@ -36,6 +37,6 @@ def balance_controller(kind):
         for j in (3, 8):                         # hip x
             a[:, j] += kr * roll + kv * vy
         a[:, 2] += ar * roll                     # abdomen x
-        return np.clip(a, -1.0, 1.0).astype(np.float32)
+        return np.clip(sigma * a, -1.0, 1.0).astype(np.float32)     # torques about +axis -> policy coordinates
 
     return act

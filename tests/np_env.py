@@ -59,8 +59,9 @@ def observation(m, st, flags, n):
     obs[3] = vw[2]
     obs[4], obs[5] = roll, pitch
     lo, hi = m["range"][:, 0], m["range"][:, 1]
-    obs[6:27] = 2.0 * (st[Q] - 0.5 * (lo + hi)) / (hi - lo)
-    obs[27:48] = 0.1 * st[QD]
+    sigma = np.asarray(M.POLICY_SIGN, np.float64)         # policy coordinates, PHYSICS.md 2
+    obs[6:27] = sigma * (2.0 * (st[Q] - 0.5 * (lo + hi)) / (hi - lo))
+    obs[27:48] = sigma * (0.1 * st[QD])
     obs[48], obs[49] = float(flags & 1), float((flags >> 1) & 1)
     obs[:50] = np.clip(obs[:50], -5.0, 5.0)
     terrain = st[65:185].reshape(NUM_STONES, 6)
@@ -77,7 +78,7 @@ def control_step(m, st, act):
     `advance` = the target would advance on this step (the caller skips the env: stone re-draw not restated here)."""
     st = np.asarray(st, np.float64).copy()
     a = np.clip(np.asarray(act, np.float64), -1.0, 1.0)
-    tau = a * m["torque"]
+    tau = np.asarray(M.POLICY_SIGN, np.float64) * a * m["torque"]      # the action is in policy coordinates, PHYSICS.md 2
     n, count, elapsed = int(st[N]), int(st[COUNT]), int(st[ELAPSED])
     terrain = st[65:185].reshape(NUM_STONES, 6)
     contacts, soles = None, None

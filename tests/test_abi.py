@@ -82,7 +82,7 @@ def test_header_is_plain_c_and_usable_without_python(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", src, "-o", exe, "-ldl"])
     out = subprocess.run([exe, lib], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert "version 3" in out.stdout and "obs_dim 60 act_dim 21" in out.stdout
+    assert "version 4" in out.stdout and "obs_dim 60 act_dim 21" in out.stdout
     import torch
     if not torch.cuda.is_available():
         assert "create rc -3" in out.stdout and "no CPU fallback" in out.stdout

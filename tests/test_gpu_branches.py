@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
+from steppingstone_amd import model
 from controllers import balance_controller
 
 torch = pytest.importorskip("torch")
@@ -147,17 +148,18 @@ def _mirror_state(st, idx):
     """y-mirror of a packed [N,185] state (include/steppingstone.h layout), using the library's own joint index lists
     (idx = ss_get_mirror_indices: neg_obs, right_obs, left_obs, neg_act, right_act, left_act) for the joints."""
     neg_a, right_a, left_a = idx[3], idx[4], idx[5]
+    sigma = np.asarray(model.POLICY_SIGN, st.dtype)   # the lists act on POLICY coordinates; the state holds angles about +axis
     m = st.copy()
     m[:, 1] *= -1                                   # pos y
     m[:, [4, 6]] *= -1                              # quat x, z
     m[:, [7, 9]] *= -1                              # angular velocity x, z (axial vector)
     m[:, 11] *= -1                                  # linear velocity y
     for base in (13, 34):                           # q, qd
-        blk = m[:, base:base + 21].copy()
+        blk = m[:, base:base + 21] * sigma
         blk[:, neg_a] *= -1
         out = blk.copy()
         out[:, right_a], out[:, left_a] = blk[:, left_a], blk[:, right_a]
-        m[:, base:base + 21] = out
+        m[:, base:base + 21] = out * sigma
     fl = st[:, 64].astype(np.int64)
     m[:, 64] = ((fl & 1) << 1) | ((fl >> 1) & 1)    # foot contact bits swap
     terr = m[:, 65:185].reshape(-1, 20, 6)

@@ -32,7 +32,7 @@ KINDS = [("Walker3DStepperEnv-v0", "walker3d"), ("MikeStepperEnv-v0", "mike")]
 def numpy_control_step(m, st, act):
     """Four substeps of PHYSICS.md 3 in numpy fp64 from a packed state; returns the 55 dynamic words, the per-foot contact flags
     of the last substep and the smallest distance of any corner to a detection threshold over the four substeps."""
-    tau = np.clip(act, -1.0, 1.0) * m["torque"]
+    tau = np.asarray(npc.M.POLICY_SIGN, np.float64) * np.clip(act, -1.0, 1.0) * m["torque"]      # action in policy coordinates
     s = st.astype(np.float64).copy()
     margin = np.inf
     feet = [False, False]

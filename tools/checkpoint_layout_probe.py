@@ -11,7 +11,8 @@ The policies were trained in the reference's own (absent) env, so their weights 
     x / z axes are themselves mirrored there), (c) random lists -- then per-index attribution (toggle one index's negation) and a
     coordinate descent over the sign bits from both starts.  The critic isolates the observation side (no M_a involved).
  2. first layer: column norms of actor.fc1 per observation entry (an input the env never varied has a small column; right / left
-    twins have similar ones) and the same for the critic.
+    twins have similar ones) and the same for the critic; 2b. the mean Jacobian d pi / d o: which 21-wide windows of the 60 inputs
+    are coupled joint-by-joint to the 21 actions (the joint-rate and joint-angle blocks, in action order).
  3. survival of the deterministic shipped policy in OUR env under cheap convention adapters between env and policy (sign of the
     left limbs' x / z joints, per-joint-type signs, velocity scale, target-block order, clipping of the action), greedy over the
     per-joint-type signs.  Mean episode length in control steps; random actions and zero actions for comparison.
@@ -74,6 +75,12 @@ def ours():
 
 def recollected():
     return Mirror({2, 4, 6, 8, 27, 29, 50, 53, 55, 58}, {0, 2})
+
+
+def round3():
+    """the lists of rounds 1-3: every x / z joint negated (left limbs measured about the +axis like the right ones)"""
+    xz = [0, 2, 3, 4, 8, 9, 13, 14, 17, 18]
+    return Mirror({2, 4, 50, 53, 55, 58} | {6 + j for j in xz} | {27 + j for j in xz}, set(xz))
 
 
 def random_mirror(rng):
@@ -179,6 +186,19 @@ def sample_observations(kind, ac, n=256, steps=24):
     return np.concatenate(out).astype(np.float32)
 
 
+def jacobian_blocks(ac, O):
+    """mean Jacobian d pi / d o over the observations: a trained controller couples action j most strongly to ITS joint's rate and
+    angle (damping / restoring terms), so the two 21-wide windows of the 60 inputs whose 21 x 21 block is diagonal-dominant are the
+    joint-rate and joint-angle blocks, in ACTION order -- a reference-held check of the layout hypothesis 6 | 21 q | 21 qd | 2 | 10."""
+    Ot = torch.from_numpy(O).clone().requires_grad_(True)
+    J = np.zeros((21, 60))
+    for j in range(21):
+        g, = torch.autograd.grad(ac.actor(Ot)[:, j].sum(), Ot)
+        J[j] = g.mean(0).numpy()
+    ratio = [(float(np.abs(np.diag(J[:, off:off + 21])).mean() / (np.abs(J[:, off:off + 21]).mean() + 1e-12)), off) for off in range(0, 40)]
+    return J, sorted(ratio, reverse=True)
+
+
 def survival(kind, ac, so, sa, n=96, steps=240, act_fn=None, clip=False, qd_scale=1.0, swap_target=False):
     o = ol.OracleEnv(kind, n, seed=9)
     o.set_curriculum(0)
@@ -234,7 +254,7 @@ def main():
         O = sample_observations(kind, ac)
         print("1. mirror equivariance on %d observations of our env (actor: mean |pi(M_o o) - M_a pi(o)|, mean |a| = %.3f; critic: mean "
               "|V(M_o o) - V(o)| / std V)" % (len(O), errors(ac, ours(), O)[2]))
-        for label, M in (("ours", ours()), ("recollected", recollected())):
+        for label, M in (("ours", ours()), ("recollected", recollected()), ("round 3", round3())):
             ea, ev, _ = errors(ac, M, O)
             print("   %-12s actor %.3f critic %.3f | %s" % (label, ea, ev, describe(M)))
         r = np.array([errors(ac, random_mirror(rng), O)[:2] for _ in range(20)])
@@ -257,6 +277,13 @@ def main():
         tw = [abs(na[6 + r] - na[6 + l]) / (na[6 + r] + na[6 + l]) for r, l in zip(RIGHT_J, LEFT_J)]
         print("   right / left twin columns (joint angles): relative norm difference mean %.3f max %.3f; contact flags %.2f vs %.2f" % (
             np.mean(tw), np.max(tw), na[48], na[49]))
+        J, ratio = jacobian_blocks(ac, O)
+        print("2b. mean Jacobian d pi / d o: 21-wide input windows ranked by diagonal dominance of their 21 x 21 block (mean |diag| / mean |block|): "
+              + ", ".join("offset %d: %.2f" % (o, r) for r, o in ratio[:5]))
+        for name, off in (("joint rates, obs[27:48]", 27), ("joint angles, obs[6:27]", 6)):
+            B = J[:, off:off + 21]
+            print("   d a_j / d (%s)_j: %s   negative for %d of 21; row maximum on the own joint for %d of 21" % (
+                name, " ".join("%+.2f" % v for v in np.diag(B)), int((np.diag(B) < 0).sum()), int((np.abs(B).argmax(1) == np.arange(21)).sum())))
         print("3. survival of the deterministic policy in OUR env (mean episode length in control steps, 96 envs x 240 steps, flat terrain;"
               " stones reached)")
         one = np.ones(60, np.float32), np.ones(21, np.float32)
@@ -265,7 +292,7 @@ def main():
         print("   policy, our conventions   %6.1f  %.2f" % survival(kind, ac, *one))
         print("   ... action clipped to +-1 %6.1f  %.2f" % survival(kind, ac, *one, clip=True))
         so, sa, types = type_sign_vectors([], True)
-        print("   left x / z joints flipped %6.1f  %.2f   (upstream's mirrored left axes, SURVEY 9)" % survival(kind, ac, so, sa))
+        print("   left x / z joints flipped %6.1f  %.2f   (the round-3 convention: left limbs about the +axis)" % survival(kind, ac, so, sa))
         for s in (0.3, 3.0, 10.0):
             print("   joint speeds x %-4g       %6.1f  %.2f" % ((s,) + survival(kind, ac, *one, qd_scale=s)))
         print("   target sin/cos swapped    %6.1f  %.2f" % survival(kind, ac, *one, swap_target=True))

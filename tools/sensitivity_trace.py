@@ -33,7 +33,7 @@ cases.sort(key=lambda c: -c[0])
 one32, one64 = ol.OracleEnv(kind, 1, seed=0), ol.OracleEnv(kind, 1, seed=0, prec="f64")
 print("%s: the 6 env-steps of 10240 on which the fp32 and fp64 builds of the oracle end farthest apart (max |obs| difference)" % kind)
 for dist, st, a in cases[:6]:
-    tau = (np.clip(a, -1, 1) * m["torque"]).astype(np.float32)
+    tau = (np.asarray(M.POLICY_SIGN) * np.clip(a, -1, 1) * m["torque"]).astype(np.float32)
     one32.set_state(st[None])
     one64.set_state(st[None].astype(np.float64))
     print("env-step with |obs32 - obs64| = %.1e" % dist)
