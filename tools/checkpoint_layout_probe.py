@@ -14,7 +14,7 @@ The policies were trained in the reference's own (absent) env, so their weights 
     twins have similar ones) and the same for the critic; 2b. the mean Jacobian d pi / d o: which 21-wide windows of the 60 inputs
     are coupled joint-by-joint to the 21 actions (the joint-rate and joint-angle blocks, in action order).
  3. survival of the deterministic shipped policy in OUR env under cheap convention adapters between env and policy (sign of the
-    left limbs' x / z joints, per-joint-type signs, velocity scale, target-block order, clipping of the action), greedy over the
+    left limbs' x / z joints, per-joint-type signs, velocity / angle / action scale, target-block order and sin / cos order, clipping of the action), greedy over the
     per-joint-type signs.  Mean episode length in control steps; random actions and zero actions for comparison.
 
   python tools/checkpoint_layout_probe.py [walker3d|mike] > profiles/r04_checkpoint_layout_<robot>.txt
@@ -199,7 +199,8 @@ def jacobian_blocks(ac, O):
     return J, sorted(ratio, reverse=True)
 
 
-def survival(kind, ac, so, sa, n=96, steps=240, act_fn=None, clip=False, qd_scale=1.0, swap_target=False):
+def survival(kind, ac, so, sa, n=96, steps=240, act_fn=None, clip=False, qd_scale=1.0, swap_target=False, act_scale=1.0, swap_blocks=False,
+             q_scale=1.0):
     o = ol.OracleEnv(kind, n, seed=9)
     o.set_curriculum(0)
     obs = o.reset()
@@ -211,10 +212,14 @@ def survival(kind, ac, so, sa, n=96, steps=240, act_fn=None, clip=False, qd_scal
             x = obs * so
             if qd_scale != 1.0:
                 x[:, 27:48] *= qd_scale
+            if q_scale != 1.0:
+                x[:, 6:27] *= q_scale
             if swap_target:
                 x[:, [50, 51, 55, 56]] = x[:, [51, 50, 56, 55]]
+            if swap_blocks:
+                x[:, 50:60] = x[:, [55, 56, 57, 58, 59, 50, 51, 52, 53, 54]]
             with torch.no_grad():
-                a = ac.actor(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).numpy() * sa
+                a = ac.actor(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).numpy() * sa * act_scale
             if clip:
                 a = np.clip(a, -1, 1)
         obs, _, d, info = o.step(a.astype(np.float32))
@@ -296,6 +301,11 @@ def main():
         for s in (0.3, 3.0, 10.0):
             print("   joint speeds x %-4g       %6.1f  %.2f" % ((s,) + survival(kind, ac, *one, qd_scale=s)))
         print("   target sin/cos swapped    %6.1f  %.2f" % survival(kind, ac, *one, swap_target=True))
+        print("   target blocks swapped     %6.1f  %.2f" % survival(kind, ac, *one, swap_blocks=True))
+        for s_ in (0.5, 2.0):
+            print("   action x %-4g (power)     %6.1f  %.2f" % ((s_,) + survival(kind, ac, *one, act_scale=s_)))
+        for s_ in (0.5, 2.0):
+            print("   joint angles x %-4g       %6.1f  %.2f   (another range normalisation)" % ((s_,) + survival(kind, ac, *one, q_scale=s_)))
         for left in (False, True):
             flips, best = [], survival(kind, ac, *type_sign_vectors([], left)[:2])[0]
             for sweep in range(2):
