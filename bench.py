@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DStepperEnv-v0"
-# ALGORITHMIC HBM bytes per env-step with this repository's state layout (DESIGN.md section 2):
+# ALGORITHMIC HBM bytes per env-step with this repository's state layout (DESIGN.md section 3):
 #   one launch per step: read 84 f32 state / stone-cache fields + 4 i32 = 352 B; write 60 f32 + 5 i32 state = 260 B,
 #                        obs 240 B, rew 4 B, done 1 B, info 24 B = 529 B                                     -> 881 B
 #   K steps per launch:  the 352 B are read once per launch, the 529 B written every step; the epilogue's re-read of
@@ -103,16 +103,16 @@ def recorded_pmc():
 def pmc_note(d):
     """The limiter statement of roofline.note, derived from the current PMC file (not hard-coded)."""
     if not d:
-        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 4.1); no PMC profile committed"
+        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 5.1); no PMC profile committed"
     w = d.get("per_wave_per_launch", {})
     cyc = w.get("SQ_WAVE_CYCLES") or 0
     if not cyc:
-        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 4.1)"
+        return "per-lane rigid-body dynamics, not HBM-bound (DESIGN.md 5.1)"
     busy = 100.0 * (w.get("SQ_ACTIVE_INST_VALU") or 0) / cyc
     wait = 100.0 * (w.get("SQ_WAIT_ANY") or 0) / cyc
     return ("not HBM-bound: per-lane rigid-body dynamics limited by VALU issue / dependent-chain latency; averaged over "
             "the %s wavefronts of a launch (main + helper wavefronts) SQ_ACTIVE_INST_VALU = %.0f %% and SQ_WAIT_ANY = "
-            "%.0f %% of wave cycles (DESIGN.md 4.1)" % (d.get("waves_per_launch", "?"), busy, wait))
+            "%.0f %% of wave cycles (DESIGN.md 5.1)" % (d.get("waves_per_launch", "?"), busy, wait))
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline

@@ -444,7 +444,7 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
 static int g_pgs_iters = PGS_ITERS;
 static int g_pgs_warm = PGS_WARM;
 void sso_debug_set_solver(int iters, int warm) { g_pgs_iters = iters; g_pgs_warm = warm; }
-/* further knobs of the same study (tools/spec_deviations.py -> DESIGN.md section 3 table): Baumgarte factor, and
+/* further knobs of the same study (tools/spec_deviations.py -> docs/HISTORY.md section 3 table): Baumgarte factor, and
  * Gauss-Seidel instead of Jacobi BETWEEN the feet (a row then sees the other foot's impulses of the same sweep) */
 static real g_erp = ERP;
 static int g_seq_feet = 0;

@@ -119,7 +119,7 @@ struct Prof { int unused; };
 // Schedule fuzzing (-DSS_FUZZ_SCHED; test builds only, tools/sched_fuzz.py): every wavefront sleeps a pseudo-random time at the
 // start of each barrier window (and at the other hand-over points of a control step), so that the relative timing of the main
 // and the helper wavefronts differs from launch to launch and from window to window.  Nothing but the barriers may order the
-// hand-off region: the fuzzed build must produce the bits of the plain build (DESIGN.md 4.1b).
+// hand-off region: the fuzzed build must produce the bits of the plain build (DESIGN.md 5.1b).
 #if defined(SS_FUZZ_SCHED) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void ss_fuzz(uint32_t site) {
   uint32_t h = (uint32_t)__builtin_amdgcn_s_memtime() ^ (site * 0x9E3779B9u);     // differs per wavefront, launch and visit

@@ -342,8 +342,9 @@ SSD float reset_angle(const uint32_t (&r)[6][4]) {
 // Global stores of a step's outputs and state rows.  -DSS_NT_STORES makes them non-temporal (`nt`) in the one-launch-per-step
 // kernels: nothing reads the rows again before the kernel ends, and a kernel boundary on this chip writes back whatever is dirty in
 // eight private L2s -- measured 0.0648 -> 0.0640 ms/step at 4096 envs (system-scope write-through stores: the same).  Off by
-// default: measured late in round 3, next to a non-reproducible one-step mismatch that the hunt could not tie to anything
-// (DESIGN.md 7); the committed profiles are of the plain stores.
+// default: 1.2 % of a secondary figure.  (Round 3 left them off because a non-reproducible one-step mismatch had shown up next to
+// them; round 4 root-caused that to copy_block's padding workgroup, DESIGN.md 5.1b -- unrelated to the stores.)  The committed
+// profiles are of the plain stores.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SS_NT_STORES)
 typedef float ss_v4f __attribute__((ext_vector_type(4)));
 template <bool NT, class T>
@@ -457,7 +458,7 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
     const int env0 = (lane_global - lane) >> 1;                                   // first env of this wavefront
     // (never negative: a wavefront without a valid env -- not launched since round 4, ss_api.hip: grid = ceil(n / 32) -- would
     // otherwise reach copy_block with nfl < 0, where `n4 << 2` rounds below nfl and lanes 0 and 1 stored two out-of-range LDS words
-    // into the reward / done slots of env n - 1's PACKED row: the schedule-dependent step of DESIGN.md 4.1b)
+    // into the reward / done slots of env n - 1's PACKED row: the schedule-dependent step of DESIGN.md 5.1b)
     const int nleft = P.n - env0;
     const int nvalid = nleft <= 0 ? 0 : (kEnvsPerWave < nleft ? kEnvsPerWave : nleft);
     // copy the staged block (nfl floats from the start of the LDS staging area) to dst: float4 when dst is 16-byte aligned
@@ -927,7 +928,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
 }
 
 #ifndef SS_HOST_HARNESS
-// Experiment (-DSS_CODE_PREFETCH=bytes, off by default; DESIGN.md 7): the helper wavefronts, idle until the main wavefront has loaded
+// Experiment (-DSS_CODE_PREFETCH=bytes, off by default; DESIGN.md 9): the helper wavefronts, idle until the main wavefront has loaded
 // the state, read the kernel's own code (from the entry point on) as data, so that the main wavefront's instruction fetches of a
 // launch's first control step find the lines in L2 instead of HBM / MALL (a kernel boundary invalidates the L2s of all eight XCDs).
 #if defined(SS_CODE_PREFETCH)
@@ -946,7 +947,7 @@ __device__ __forceinline__ void prefetch_code(unsigned long long entry_pc, int h
 #endif
 // Layout experiment (-DSS_ENTRY_PAD=n / -DSS_HELPER_PAD=n: n `s_nop`s, 4 bytes each, executed once per launch at the kernel's entry /
 // at the head of the helper wavefronts' branch): the helped kernels are 77-85 KB of code against a 64 KB instruction cache shared by
-// two CUs, so where the main and the helper wavefronts' hot code falls in the cache is worth a few per cent (DESIGN.md 7).
+// two CUs, so where the main and the helper wavefronts' hot code falls in the cache is worth a few per cent (DESIGN.md 9).
 #define SS_STR2(x) #x
 #define SS_STR(x) SS_STR2(x)
 #if defined(SS_ENTRY_PAD) && defined(__HIP_DEVICE_COMPILE__)

@@ -1,4 +1,4 @@
-"""Peer-store all-gather (DESIGN.md "multi-GPU"): the per-step exchange of the packed [N/G,62] block
+"""Peer-store all-gather: the per-step exchange of the packed [N/G,62] block
 WITHOUT a collective in the data path.  The step kernel of every rank stores its rows straight into every peer's gather
 buffer over xGMI (ss_step_packed_peers) and the last workgroup publishes the step number in the peers' flag words;
 consumers wait on their own flag array (ss_peer_wait, one wavefront).  Buffers live in fine-grained device memory

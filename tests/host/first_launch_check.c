@@ -1,5 +1,5 @@
 /* In-launch self-check of the HIP env kernels, meant to be run as a FRESH PROCESS many times (tests/test_gpu_first_launch.py;
- * DESIGN.md 4.1b): a plain-C client of include/steppingstone.h (dlopen) with the HIP runtime for the buffers -- no Python, no torch.
+ * DESIGN.md 5.1b): a plain-C client of include/steppingstone.h (dlopen) with the HIP runtime for the buffers -- no Python, no torch.
  *
  *   first_launch_check LIB KIND N INPUT MODE [REPEATS]
  *     LIB    path of libsteppingstone.so          KIND  0 Walker3D, 1 Mike          N  a power of two

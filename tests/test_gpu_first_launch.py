@@ -1,4 +1,4 @@
-"""The first launch of a fresh process, checked from inside the launch (VERDICT r3 item 1; DESIGN.md 4.1b).
+"""The first launch of a fresh process, checked from inside the launch (VERDICT r3 item 1; DESIGN.md 5.1b).
 
 Round 3 twice saw the FIRST step of a new environment differ from identical repetitions after it (about one step in 1e5).  A first
 launch fetches its code through a cold instruction cache, so the main and the helper wavefronts of a workgroup run with a relative

@@ -9,7 +9,7 @@ inputs -- nothing of oracle/ is evaluated between the inputs and the comparison 
 states).  Env-steps on which the target advances are skipped (stone re-draw: Philox, pinned bit-exactly elsewhere).
 
 Tolerance (fp32 kernel against an fp64 evaluation, PHYSICS.md's amplification of rounding on a pivoting foot included, see
-DESIGN.md section 3): joint angles / base pose within 2e-6 in the median and 5e-5 at worst (measured 1.7e-7 / 6.6e-6);
+docs/HISTORY.md section 3): joint angles / base pose within 2e-6 in the median and 5e-5 at worst (measured 1.7e-7 / 6.6e-6);
 generalised velocities (O(1..10) rad/s) within 1e-4 in the median, 1e-3 for 99 % of the env-steps and 5e-3 at worst (measured
 1.7e-5 / 2.3e-4 / 4.0e-4); OBSERVATIONS within the north star's 1e-4 on every env-step (measured 4.0e-5 at worst, 1.8e-6 median)
 and REWARDS within 1e-3 (measured 8.2e-5) away from the reward's own discontinuities (posture / joint-limit / height thresholds

@@ -1,4 +1,4 @@
-"""Schedule fuzzing as a standing test (VERDICT r3 item 1; DESIGN.md 4.1b): the -DSS_FUZZ_SCHED build of the product's own kernel
+"""Schedule fuzzing as a standing test (VERDICT r3 item 1; DESIGN.md 5.1b): the -DSS_FUZZ_SCHED build of the product's own kernel
 sources (steppingstone_amd/lib/libsteppingstone_fuzz.so, built by steppingstone_amd.build.build_fuzz) makes every wavefront sleep a
 pseudo-random time -- seeded by the shader clock, so different in every run -- at the start of every barrier window of the main /
 helper schedule and at the hand-over points of a control step.  Its results must be the bits of the product library on every

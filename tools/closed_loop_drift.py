@@ -3,7 +3,7 @@ controller (tests/controllers.py): fp32 CPU oracle vs fp64 CPU oracle, and -- wh
 both.  Each implementation computes its actions from ITS OWN observations; the seeded action noise is shared.
    python tools/closed_loop_drift.py [walker3d|mike] [noise=0.05] [envs=32]
 Prints, every 100 steps, the median / max |obs| distance between the implementations over the robots still alive in all
-of them.  (Runs on the CPU-only container for the two oracle builds; DESIGN.md section 3 quotes its output.)"""
+of them.  (Runs on the CPU-only container for the two oracle builds; docs/HISTORY.md section 3 quotes its output.)"""
 import os
 import sys
 

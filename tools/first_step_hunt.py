@@ -1,4 +1,4 @@
-"""Hunt for the non-reproducible FIRST step (run on the GPU box; DESIGN.md 4.1b).  Round 3 saw, twice, the first step of a new
+"""Hunt for the non-reproducible FIRST step (run on the GPU box; DESIGN.md 5.1b).  Round 3 saw, twice, the first step of a new
 environment come out different from identical repetitions after it (numpy drop-in mode both times).  Two in-process reproductions
 of "first":
 

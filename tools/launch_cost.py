@@ -1,5 +1,5 @@
 """Cost of a rollout launch as a function of its length (run on the GPU box): HIP-event time of launches of K control steps at 4096
-envs, back to back and with idle gaps between them.  DESIGN.md 4.1a quotes the table."""
+envs, back to back and with idle gaps between them.  docs/HISTORY.md 4.1a quotes the table."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

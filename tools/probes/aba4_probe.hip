@@ -1,5 +1,5 @@
 // aba4_probe.hip -- does spreading the 6x6 algebra of ONE pass-2 joint step of the ABA over a DPP lane pair pay?  (VERDICT r3 item 3;
-// DESIGN.md 7 "four lanes per env": until now estimated by instruction count only.)
+// DESIGN.md 9 / docs/HISTORY.md 7 "four lanes per env": until now estimated by instruction count only.)
 //
 // The env kernels run two lanes per env (one per half body); "four lanes per env" means two lanes per half-body chain.  Lanes of a
 // wavefront execute ONE instruction stream, so the two lanes of a chain can only share a joint step if they run the SAME operation

@@ -1,5 +1,5 @@
 // 160 KiB of straight-line VALU code per wavefront: run on every CU, it evicts the 64 KiB instruction cache a CU pair shares, so
-// that the next kernel fetches its code cold, as the first launch of a process does (tools/first_step_hunt.py, DESIGN.md 4.1b).
+// that the next kernel fetches its code cold, as the first launch of a process does (tools/first_step_hunt.py, DESIGN.md 5.1b).
 //   hipcc --offload-arch=gfx950 -O2 -fPIC -shared tools/probes/icache_evict.hip -o var/libicache_evict.so
 #include <hip/hip_runtime.h>
 

@@ -1,4 +1,4 @@
-"""Schedule-fuzz fingerprint (run on the GPU box; DESIGN.md 4.1b).
+"""Schedule-fuzz fingerprint (run on the GPU box; DESIGN.md 5.1b).
 
     python tools/sched_fuzz.py [ENV_STEPS_PER_CONFIG [TINY_STEPS]]                   -> one line per configuration: a position-sensitive
                                                                               checksum of EVERY step's packed [N,62] block
@@ -26,7 +26,7 @@ TARGET = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 TINY_STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 CHUNK = 32
 # ragged tiny batches: n mod 64 in 1..32 is where the array padding (64 envs) exceeds the launch's last 32-env workgroup -- the odd
-# ones (1, 3, 5, 31, 65, 67) are the batch sizes whose packed row of env n - 1 was schedule-dependent until round 4 (DESIGN.md 4.1b)
+# ones (1, 3, 5, 31, 65, 67) are the batch sizes whose packed row of env n - 1 was schedule-dependent until round 4 (DESIGN.md 5.1b)
 TINY = (1, 3, 5, 31, 33, 65, 67, 700)
 
 

@@ -2,7 +2,7 @@
 action, substep by substep).  Picks the env-steps of a curriculum-5 random-action rollout on which the two builds end farthest
 apart and prints, per substep, the active sole corners and the distance between the two builds in: the Delassus operator, the
 free foot twist, the solved impulses, the joint-rate change applied by the contact stage, and the state.  The pattern it shows
-(DESIGN.md section 3): an error of ~1e-6 in the free foot twist becomes ~1e-5 in the impulses and ~1e-4 in the ankle rate within
+(docs/HISTORY.md section 3): an error of ~1e-6 in the free foot twist becomes ~1e-5 in the impulses and ~1e-4 in the ankle rate within
 one substep (joints 7 / 12: the ankles), and the ankle rate feeds the next substep's foot twist.
 usage: python tools/sensitivity_trace.py [kind] > profiles/r03_sensitivity_trace.txt"""
 import os

@@ -3,7 +3,7 @@ recollection of Bullet's defaults -- on the fp64 oracle, this container, no GPU.
 random-action rollouts (curriculum 5) and of robots standing under a PD controller, against the specified solve
 (8 cold sweeps, ERP 0.2, Jacobi between the feet): relative change of the post-step velocities of the env-steps that are
 in contact, plus the steady-state sole penetration of a standing robot and the joint-limit overshoot.  The table
-goes into DESIGN.md section 3.  usage: python tools/spec_deviations.py"""
+goes into docs/HISTORY.md section 3.  usage: python tools/spec_deviations.py"""
 import ctypes as C
 import os
 import sys
