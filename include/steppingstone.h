@@ -72,10 +72,11 @@ const char* ss_last_error(void);
 
 /* Joint conventions.  Joint / action order: common/render_utils.py:47-69 (abdomen z,y,x; right hip x,z,y, knee, ankle; left ...;
  * right shoulder x,z,y, elbow; left ...).  POLICY coordinates -- act[j], obs[6+j] (normalised angle), obs[27+j] (0.1 * rate):
- * about the +axis of the link frame for the spine and the right limbs and about the MIRRORED axis for the left limbs' x / z
- * joints (docs/PHYSICS.md 2, sigma = model.POLICY_SIGN), so that ss_get_mirror_indices swaps the limbs without negating them:
- * the convention the reference's shipped actors were trained in (playground/models/ *.pt are mirror-equivariant under exactly
- * these lists, tests/test_shipped_policy_layout.py).  ss_get_state / ss_set_state keep every angle about the +axis.
+ * sigma_j x (value about the +axis of the link frame), docs/PHYSICS.md 2, sigma = model.POLICY_SIGN: -1 for the left limbs' x / z
+ * joints (measured about the MIRRORED axis, so that ss_get_mirror_indices swaps the limbs without negating them) and for both knees
+ * (negative in flexion), +1 elsewhere: the conventions the reference's shipped actors were trained in (playground/models/ *.pt are
+ * mirror-equivariant under exactly these lists and reject the other knee sign, tests/test_shipped_policy_layout.py).
+ * ss_get_state / ss_set_state keep every angle about the +axis.
  *
  * ShmemVecEnv.reset (envs_utils.py:542-548): obs [num_envs, 60] f32 row-major, device pointer. */
 int ss_reset(ss_env* env, float* obs, void* stream);
@@ -165,7 +166,7 @@ int ss_get_obs(ss_env* env, float* obs, void* stream);
 int32_t ss_num_envs(const ss_env* env);
 /* SS_ABI_VERSION of the library.  A binding must check it at load time (steppingstone_amd/_lib.py does): version 2 inserted
  * steps_per_launch into ss_rollout_random's argument list, version 3 grew ss_info to 6 words and the packed state to 186,
- * version 4 changed the sign convention of the left limbs' x / z joints in actions and observations (same layouts). */
+ * version 4 changed the sign convention of the left limbs' x / z joints and of the knees in actions and observations (same layouts). */
 int ss_version(void);
 
 /* Measurement aids (tools/hbm_traffic.py, tools/phase_profile.py); not part of the env protocol.

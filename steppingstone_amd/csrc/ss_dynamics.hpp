@@ -76,13 +76,18 @@ static_assert(S_END <= (kLdsSlots - kSlotsA) * 4, "LDS scalar region overflow");
 constexpr int kHalf[NH] = {0, 1, 2, 3, 4, 5, 6, 7, 13, 14, 15, 16};
 // joints whose angle changes sign under the y-mirror (rotation about x or z)
 constexpr bool mirror_flips(int j) { return kAxis[j] != 1; }
-// Policy coordinates (PHYSICS.md 2, kPolicySign): actions and observations measure the LEFT limbs' x / z joints about the
-// mirrored axis.  The left lane's mirrored world holds exactly that value for its limbs, so
-//   action (policy) -> lane world: only the spine's z / x joints change sign in the left lane;
-//   lane's TRUE-world angle -> observation: the left limbs' x / z joints change sign.
-// (tools/gen_model_tables.py asserts kPolicySign is -1 exactly on the left limbs' x / z joints.)
-__host__ __device__ constexpr float action_lane_sign(int jr, float m) { return (jr < 3 && mirror_flips(jr)) ? m : 1.f; }
-__host__ __device__ constexpr float policy_lane_sign(int jr, int side) { return (jr >= 3 && mirror_flips(jr) && side) ? -1.f : 1.f; }
+// Policy coordinates (PHYSICS.md 2, kPolicySign): actions and observations carry sigma_j x (value about the +axis).  For the limbs
+// sigma is one physical convention on both sides (the generator asserts sigma[left] = sigma[right] for y joints and -sigma[right] for
+// x / z joints: the left one is measured about the mirrored axis), and the left lane's mirrored world holds exactly "about the
+// mirrored axis" -- so BOTH lanes convert between their own world and policy coordinates with the RIGHT twin's sigma; the spine
+// (sigma = +1) changes sign in the left lane for its z / x joints only.  The same factor serves actions in and observations out.
+__host__ __device__ constexpr float action_lane_sign(int jr, float m) {
+  return jr < 3 ? (mirror_flips(jr) ? m : 1.f) : (float)kPolicySign[jr];
+}
+// TRUE-world value (about the +axis, as the state arrays hold it) -> policy coordinates: sigma of the joint itself
+__host__ __device__ constexpr float policy_true_sign(int jr, int side) {
+  return jr < 3 ? 1.f : (float)kPolicySign[jr] * ((mirror_flips(jr) && side) ? -1.f : 1.f);
+}
 // highest-index child of body b inside the half-tree; -1 for leaves
 constexpr int first_child_half(int b) {
   int r = -1;

@@ -400,15 +400,17 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
       constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
       const int gj = side ? jl : jr;
       if (jr >= 3 || side == 0) {
-        // The observation carries POLICY coordinates (PHYSICS.md 2: kPolicySign = -1 for the left limbs' x / z joints,
-        // i.e. the angle about the mirrored axis) -- the left lane's own mirrored-world value, normalised with the RIGHT
-        // twin's range (a left x / z joint's true range is (-hi, -lo)).  The state arrays keep angles about the +axis.
+        // The observation carries POLICY coordinates (PHYSICS.md 2): ps = kPolicySign of THIS joint (left x / z joints: about the
+        // mirrored axis; knees: negative in flexion), applied to the true-world angle and to the middle of its true range (a left
+        // x / z joint's true range is (-hi, -lo) of its right twin's).  Same expression, same bits as write_obs.  The state arrays
+        // keep angles about the +axis.
         constexpr float midr = 0.5f * (Model::lo[jr] + Model::hi[jr]);
         constexpr float span = Model::hi[jr] - Model::lo[jr];
-        const float ps = policy_lane_sign(jr, side);
+        const float ps = policy_true_sign(jr, side);
+        const float mid = (side && mirror_flips(jr)) ? -midr : midr;
         gst<!ROLLOUT>(&Fo[(F_Q + gj) * np], o.qt[k]);
         gst<!ROLLOUT>(&Fo[(F_QD + gj) * np], o.qdt[k]);
-        SS_OBS(6 + gj) = clip5(2.f * (ps * o.qt[k] - midr) / span);
+        SS_OBS(6 + gj) = clip5(2.f * (ps * o.qt[k] - ps * mid) / span);
         SS_OBS(27 + gj) = clip5(0.1f * (ps * o.qdt[k]));
       }
     });

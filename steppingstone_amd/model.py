@@ -47,16 +47,20 @@ RIGHT_FOOT_BODY = 8    # child of right_ankle (joint 7)
 LEFT_FOOT_BODY = 13    # child of left_ankle  (joint 12)
 
 # POLICY-FACING joint coordinates (docs/PHYSICS.md section 2): what the action and the observation carry is
-# sigma_j * (torque, angle, rate about the +axis of the link frame).  sigma = -1 for the LEFT limbs' x and z joints: the
-# reference's env measures them about the mirrored axis, so that a left/right mirror of the policy's view swaps the
-# limbs WITHOUT negating them.  Evidence held by the reference: the shipped actors (playground/models/*.pt, trained
-# with common/envs_utils.py:687-740 on the env's own get_mirror_indices()) are mirror-equivariant to 0.06-0.08 under
-# exactly these lists and to 0.36-0.45 (random: 0.43-0.54) with the left x / z joints negated
-# (tools/checkpoint_layout_probe.py, profiles/r04_checkpoint_layout_*.txt).  The dynamics (state, oracle, kernels)
-# keep angles about the +axis; sigma is applied where actions enter and observations leave.
+# sigma_j * (torque, angle, rate about the +axis of the link frame).  The dynamics (state, oracle, kernels) keep angles about
+# the +axis; sigma is applied where actions enter and observations leave.  Both entries are pinned by the reference's SHIPPED
+# actors (playground/models/*.pt; tools/checkpoint_layout_probe.py, tests/test_shipped_policy_layout.py):
+#  * sigma = -1 for the LEFT limbs' x and z joints: the reference's env measures them about the mirrored axis, so that a
+#    left/right mirror of the policy's view swaps the limbs WITHOUT negating them.  The actors (trained with
+#    common/envs_utils.py:687-740 on the env's own get_mirror_indices()) are mirror-equivariant to 0.06-0.08 under exactly
+#    these lists and to 0.36-0.45 (random: 0.43-0.54) with the left x / z joints negated.
+#  * sigma = -1 for both KNEES: the reference's knee angle is negative in flexion (an MJCF knee with axis "0 -1 0", range
+#    "-160 -2").  Of the 12 joint types it is the one whose sign the shipped policies reject in our env: with it
+#    flipped the deterministic Walker3D / Mike policies stay up 81 / 58 control steps instead of 25 / 10 and start reaching the
+#    second stone, while flipping any ONE of the other 11 types changes nothing or hurts (profiles/r04_v4_checkpoint_layout_*).
 POLICY_SIGN = [1, 1, 1,
-               1, 1, 1, 1, 1,
-               -1, -1, 1, 1, 1,
+               1, 1, 1, -1, 1,
+               -1, -1, 1, -1, 1,
                1, 1, 1, 1,
                -1, -1, 1, 1]
 # get_mirror_indices() in policy coordinates: the spine's z and x joints negate in place, the limbs swap.

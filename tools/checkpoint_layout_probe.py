@@ -306,6 +306,9 @@ def main():
             print("   action x %-4g (power)     %6.1f  %.2f" % ((s_,) + survival(kind, ac, *one, act_scale=s_)))
         for s_ in (0.5, 2.0):
             print("   joint angles x %-4g       %6.1f  %.2f   (another range normalisation)" % ((s_,) + survival(kind, ac, *one, q_scale=s_)))
+        so0, sa0, types0 = type_sign_vectors([], False)
+        print("   one joint type flipped (env <-> policy sign of angle, rate and action; both sides): " + "  ".join(
+            "%s %.1f" % (t, survival(kind, ac, *type_sign_vectors([t], False)[:2])[0]) for t in types0))
         for left in (False, True):
             flips, best = [], survival(kind, ac, *type_sign_vectors([], left)[:2])[0]
             for sweep in range(2):
