@@ -306,6 +306,12 @@ def main():
             print("   action x %-4g (power)     %6.1f  %.2f" % ((s_,) + survival(kind, ac, *one, act_scale=s_)))
         for s_ in (0.5, 2.0):
             print("   joint angles x %-4g       %6.1f  %.2f   (another range normalisation)" % ((s_,) + survival(kind, ac, *one, q_scale=s_)))
+        feats = []
+        for grp in ([0], [1], [2], [3], [4], [5], [50, 55], [51, 56], [52, 57], [53, 58], [54, 59], [48, 49]):
+            so_ = np.ones(60, np.float32)
+            so_[grp] = -1
+            feats.append("%s %.1f" % ("+".join(OBS_NAMES[g] for g in grp), survival(kind, ac, so_, one[1])[0]))
+        print("   one non-joint observation feature negated between env and policy (both targets together): " + "  ".join(feats))
         so0, sa0, types0 = type_sign_vectors([], False)
         print("   one joint type flipped (env <-> policy sign of angle, rate and action; both sides): " + "  ".join(
             "%s %.1f" % (t, survival(kind, ac, *type_sign_vectors([t], False)[:2])[0]) for t in types0))
