@@ -49,3 +49,8 @@ for env_id, kind in (("Walker3DStepperEnv-v0", "walker3d"), ("MikeStepperEnv-v0"
         print("   observation bound: max %.1e; env-steps with a bound beyond its ceiling (%.0e obs / pose, %.0e velocities / reward): %d = %.4f %%; "
               "env-steps held to 1e-4: %.1f %%" % (R["tol"].max(), pr.OBS_CEIL, pr.VEL_CEIL, int(R["loose"].sum()), 100.0 * R["loose"].mean(),
                                                   100.0 * (R["category"] == 0).mean()), flush=True)
+        for i in np.nonzero(~R["ok"] | R["beyond"])[0][:8]:
+            print("   %s env-step %d: category %d near %s | obs err %.2e / bound %.2e | reward %.2e / %.2e | pose %.2e / %.2e | velocities %.2e / %.2e | "
+                  "integers equal %s" % ("FAILED" if not R["ok"][i] else "beyond its bound (counted)", i, R["category"][i], bool(R["near"][i]), R["matched_e"][i],
+                                        R["tol"][i], R["e_rew"][i], R["tol_rew"][i], R["e_pose"][i], R["tol_pose"][i], R["e_vel"][i], R["tol_vel"][i],
+                                        bool(R["int_ok"][i])), flush=True)
