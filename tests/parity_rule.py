@@ -17,7 +17,7 @@ Every env-step is bounded -- none passes on an allowance:
                (measured 0.10 - 0.13); outside 2 x the bound is a failure.  (Round 4: one env-step of a 15 360-step test reached 1.03.)
   loose bounds: an env-step whose bound exceeds 5e-3 (observation, pose) or 5e-2 (velocities, reward) is counted (`loose`); the tests
                assert that such steps stay below 1 % of the env-steps (measured: 0.4 % of a fall-heavy CPU sample of 10 240, see
-               profiles/r04_v2_parity_rule_stats.txt for the GPU sample: a foot pivoting on one corner, a body spinning up before the
+               profiles/r04_v5_parity_rule_stats.txt for the GPU sample: a foot pivoting on one corner, a body spinning up before the
                episode ends).  A hard cap instead fails the CPU's own fp32 build on those steps (round 4 tried 5e-3 / 5e-2: 26
                "failures" of 327 680 env-steps, every one of them a capped bound with the error inside 8 s)
 
