@@ -137,7 +137,10 @@ int ss_set_sample_prob(ss_env* env, const double* prob, int per_env);
  * transpose and the switch to the new grid are ordered on `stream`, the host is not synchronised (the first per-env
  * call allocates the [121][N] table). */
 int ss_set_sample_prob_device(ss_env* env, const float* prob, int per_env, void* stream);
-int ss_set_mirror(ss_env* env, int32_t on);                     /* env.set_mirror (train.py:109) */
+/* env.set_mirror (common/envs_utils.py:588-590, train.py:109-111).  Accepted for protocol compatibility ONLY -- it stores
+ * nothing and changes nothing: the Walker3D / Mike observation has no gait-phase term for the flag to act on (the reference
+ * uses it with phase-clocked envs); the symmetry a learner needs is ss_get_mirror_indices. */
+int ss_set_mirror(ss_env* env, int32_t on);
 int ss_set_power(ss_env* env, float power);                     /* env.set_robot_params({"power": p}) */
 /* on (default): worker semantics, a finished env is reset inside the step (envs_utils.py:647-648);
  * off: plain gym env semantics for make_env() users -- terminal obs returned, caller resets (train.py:243-244). */

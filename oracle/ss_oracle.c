@@ -837,10 +837,22 @@ static void fill_window(float* prob, int c, int ring) {
   for (int k = 0; k < NCELL; ++k) prob[k] = prob[k] / (float)cnt;
 }
 
+/* Model override (tools/sysid_policy.py ONLY: the informational search over the specification's free numbers against the
+ * reference's shipped policies).  Environments created AFTER the call use the given tables instead of the
+ * compiled-in ones; no test and nothing in the package calls it, so the specification the parity tests judge is SSO_MODELS. */
+static sso_model g_model_override[2];
+static int g_model_overridden[2] = {0, 0};
+void sso_debug_set_model(int kind, const sso_model* m) {
+  if (kind < 0 || kind > 1) return;
+  if (m) { g_model_override[kind] = *m; g_model_overridden[kind] = 1; } else g_model_overridden[kind] = 0;
+}
+int sso_model_size(void) { return (int)sizeof(sso_model); }
+
 sso_env* sso_create(int kind, int num_envs, uint64_t seed, int64_t env_offset) {
   sso_env* E = (sso_env*)calloc(1, sizeof *E);
   E->kind = kind; E->num_envs = num_envs; E->seed = seed; E->env_offset = env_offset;
-  E->M = &SSO_MODELS[kind]; E->power = 1; E->curriculum = 0; E->auto_reset = 1;
+  E->M = g_model_overridden[kind] ? &g_model_override[kind] : &SSO_MODELS[kind];
+  E->power = 1; E->curriculum = 0; E->auto_reset = 1;
   E->e = (env_state*)calloc((size_t)num_envs, sizeof(env_state));
   for (int e = 0; e < num_envs; ++e) { fill_window(E->e[e].prob, 0, 0); E->e[e].quat[0] = 1; }
   return E;

@@ -55,7 +55,7 @@ LEARNER_SRC = os.path.join(CSRC, "ss_learner.hip")
 
 
 def build_learner(force=False, verbose=False):
-    """The fused PPO minibatch step (csrc/ss_learner.hip, include/steppingstone_learner.h): MFMA f32 kernels, its own library."""
+    """OPT-IN (SS_BUILD_LEARNER=1 or `python -m steppingstone_amd.build --learner`).  The fused PPO minibatch step (csrc/ss_learner.hip, include/steppingstone_learner.h): MFMA f32 kernels, its own library."""
     deps = [LEARNER_SRC, os.path.join(PKG, "..", "include", "steppingstone_learner.h")]
     if not force and os.path.exists(LEARNER_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LEARNER_LIB) for d in deps):
         return LEARNER_LIB
@@ -116,7 +116,9 @@ def build_fuzz(force=False, verbose=False):
 
 
 def build(force=False, verbose=False):
-    build_learner(force, verbose)
+    # the fused PPO learner is outside SURVEY section 8's path (opt-in, frozen): built only on request
+    if os.environ.get("SS_BUILD_LEARNER", "0") not in ("", "0"):
+        build_learner(force, verbose)
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -125,6 +127,8 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--learner" in sys.argv:
+        build_learner(force="--force" in sys.argv, verbose=True)
     if "--fuzz" in sys.argv:
         build_fuzz(force="--force" in sys.argv, verbose=True)
     print(LIB)

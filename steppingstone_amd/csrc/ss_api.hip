@@ -45,7 +45,6 @@ struct ss_env {
   float* obs_rows;      // [n][60] scratch: current observation rows for create_temp_states
   int helpers;          // -1 auto, else 0 / 1 / 3 helper wavefronts (env SS_HELPERS)
   int helper_max_groups;  // auto: use the helper wavefront up to this many 32-env groups
-  int mirror;           // env.set_mirror flag (kept; see ss_set_mirror)
   ss::PeerTable* peer_table;   // device copy of the peer-store table (ss_peer_connect), or null
   uint32_t* peer_counter;
   uint32_t* peer_error;
@@ -427,12 +426,12 @@ int ss_set_sample_prob_device(ss_env* env, const float* prob, int per_env, void*
 
 int ss_set_mirror(ss_env* env, int32_t on) {
   if (!env) return fail(SS_ERR_INVALID, "null handle");
-  // The reference forwards set_mirror to every env (common/envs_utils.py:588-590; playground/train.py:109-111 with
-  // use_phase_mirror).  It matters for gait-phase-clocked envs (the Cassie stepper of train.py:37): their observation
-  // carries a phase variable that mirroring must shift by half a cycle.  Walker3D / Mike steppers have no phase clock
-  // (docs/PHYSICS.md 5: nothing in the 60-float observation depends on one), so the flag changes nothing here; that the
-  // mirror index lists alone make a correct symmetry is pinned by tests/test_gpu_parity.py::test_mirror_equivariance.
-  env->mirror = on ? 1 : 0;
+  // ACCEPTED FOR PROTOCOL COMPATIBILITY ONLY: no state, no effect.  The reference forwards set_mirror to every env
+  // (common/envs_utils.py:588-590; playground/train.py:109-111 under use_phase_mirror).  What an env does with it is in the
+  // absent mocca_envs; the only consumer visible in the reference is the gait-phase-clocked Cassie stepper of train.py:37, whose
+  // observation carries a phase variable.  The 60-float Walker3D / Mike observation (docs/PHYSICS.md 5) has no phase term, so there
+  // is nothing for the flag to shift; the mirror symmetry itself is carried by ss_get_mirror_indices.
+  (void)on;
   return SS_OK;
 }
 

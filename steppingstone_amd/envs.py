@@ -343,6 +343,8 @@ class SteppingStoneVecEnv:
         return out.cpu().numpy() if self.return_numpy else out
 
     def set_mirror(self, mirror):
+        """common/envs_utils.py:588-590.  Accepted for protocol compatibility only: no effect on Walker3D / Mike (their observation has
+        no gait-phase term; include/steppingstone.h ss_set_mirror).  The symmetry itself is get_mirror_indices()."""
         self.backend.set_mirror(bool(mirror))
 
     def set_env_params(self, params_dict):

@@ -60,18 +60,31 @@ class _U(pickle.Unpickler):
         raise pickle.UnpicklingError(pid)
 
 
+class _Plain(pickle.Unpickler):
+    """The four header / trailer records (magic, protocol, sys-info dict, storage-key list) are plain ints, dicts, strings and
+    lists: a record that names ANY global is not one of them and is refused -- nothing in the file is ever executed."""
+
+    def find_class(self, mod, name):
+        raise pickle.UnpicklingError("header record of a legacy checkpoint names a global (%s.%s): refused" % (mod, name))
+
+    def persistent_load(self, pid):
+        raise pickle.UnpicklingError("header record of a legacy checkpoint holds a persistent id: refused")
+
+
 def read_legacy(path):
     """(module object of stubs, {storage key: 1-D numpy array in the storage's own dtype})."""
     with open(path, "rb") as f:
-        magic = pickle.load(f)
+        magic = _Plain(f).load()
         if magic != _MAGIC:
             raise ValueError("%s is not a legacy (pre-zip) torch.save file (magic %r)" % (path, magic))
-        pickle.load(f)                                # protocol version
-        pickle.load(f)                                # sys info
+        _Plain(f).load()                              # protocol version
+        _Plain(f).load()                              # sys info
         u = _U(f)
         u.storage_types = {}
         obj = u.load()
-        keys = pickle.load(f)
+        keys = _Plain(f).load()
+        if not isinstance(keys, (list, tuple)):
+            raise ValueError("%s: storage-key record is %r, not a list" % (path, type(keys).__name__))
         storages = {}
         for k in keys:
             n = struct.unpack("<q", f.read(8))[0]

@@ -113,9 +113,83 @@ def _deg(lo, hi):
 
 
 # ---------------------------------------------------------------- robot definitions
-def _humanoid(scale_leg, scale_arm, torso_w, mass_scale, gains, z_extra_head):
-    """Shared topology; dimension knobs distinguish Walker3D from Mike."""
+JOINT_TYPES = ["abdomen_z", "abdomen_y", "abdomen_x", "hip_x", "hip_z", "hip_y", "knee", "ankle",
+               "shoulder_x", "shoulder_z", "shoulder_y", "elbow"]
+MASS_GROUPS = ["torso", "lwaist", "pelvis", "thigh", "shin", "foot", "upper_arm", "lower_arm"]
+
+# Every free number of the robot specification, by name (docs/PHYSICS.md section 2).  `build(kind)` evaluates DEFAULTS[kind]; a
+# caller may pass `overrides` (tools/sysid_policy.py searches over them; nothing in the package does).
+#   ranges are degrees about the +axis of the RIGHT side's link frame (the left side is the mirror image)
+_COMMON = dict(
+    density=DENSITY,
+    mass_mult={g: 1.0 for g in MASS_GROUPS},          # per link group, on top of the primitive's density mass (and its inertia)
+    spine_r0=(-0.01, -0.195), spine_r2=-0.13,         # abdomen_z origin in the torso frame (x, z); abdomen_x below abdomen_y
+    hip_y=0.10, hip_z=-0.14,                          # hip origin in the pelvis frame (|y|, z)
+    thigh=0.34, knee_gap=0.043, shin=0.30, ankle_gap=0.05,      # x leg_scale
+    thigh_radius=0.06, shin_radius=0.049,
+    foot_box_c=(0.04, -0.05), foot_box_half=(0.10, 0.05, 0.025),  # centre (x, z), half extents
+    sole=(0.14, -0.06, 0.05, -0.075),                 # sole corners: x front, x back, |y|, z (foot frame)
+    upper_arm=0.28, lower_arm=0.25, shoulder_z=0.06, shoulder_out=0.10,   # x arm_scale (lengths)
+    range={"abdomen_z": (-45, 45), "abdomen_y": (-75, 30), "abdomen_x": (-35, 35),
+           "hip_x": (-25, 5), "hip_z": (-60, 35), "hip_y": (-110, 20), "knee": (2, 160), "ankle": (-50, 50),
+           "shoulder_x": (-120, 30), "shoulder_z": (-60, 60), "shoulder_y": (-120, 60), "elbow": (-140, -2)},
+    damping={"abdomen_z": 5, "abdomen_y": 5, "abdomen_x": 5, "hip_x": 5, "hip_z": 5, "hip_y": 5,
+             "knee": 1, "ankle": 1, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 1},
+    stiffness={"abdomen_z": 20, "abdomen_y": 10, "abdomen_x": 10, "hip_x": 10, "hip_z": 10, "hip_y": 20,
+               "knee": 1, "ankle": 0, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 0},
+    armature={"abdomen_z": .02, "abdomen_y": .02, "abdomen_x": .02, "hip_x": .01, "hip_z": .01, "hip_y": .01,
+              "knee": .006, "ankle": .004, "shoulder_x": .004, "shoulder_z": .004, "shoulder_y": .004, "elbow": .003},
+    k_lim_per_torque=50.0,        # unilateral limit spring  [N m / rad] per N m of torque limit
+    d_lim_per_k=0.02,             # limit damper (active only in violation) [N m s / rad] per N m / rad
+    q0_deg={"hip_y": -12.0, "knee": 24.0, "ankle": -12.0, "elbow": -20.0},     # nominal pose: slight crouch, sole level
+    friction=0.9,
+)
+DEFAULTS = {
+    "walker3d": dict(_COMMON, leg_scale=1.0, arm_scale=1.0, torso_w=0.07, mass_scale=1.0, head_extra=0.0,
+                     torque={"abdomen_z": 60, "abdomen_y": 80, "abdomen_x": 60, "hip_x": 80, "hip_z": 60, "hip_y": 100, "knee": 90,
+                             "ankle": 60, "shoulder_x": 60, "shoulder_z": 60, "shoulder_y": 50, "elbow": 60}),
+    # Mike: stockier body, shorter limbs, stronger legs (own numbers; upstream asset absent)
+    "mike": dict(_COMMON, leg_scale=0.85, arm_scale=0.9, torso_w=0.11, mass_scale=1.25, head_extra=0.04,
+                 torque={"abdomen_z": 80, "abdomen_y": 100, "abdomen_x": 80, "hip_x": 100, "hip_z": 80, "hip_y": 130, "knee": 120,
+                         "ankle": 80, "shoulder_x": 60, "shoulder_z": 60, "shoulder_y": 50, "elbow": 60}),
+}
+
+
+def params(kind, overrides=None):
+    """DEFAULTS[kind] with `overrides` applied: {"thigh": 0.36, "torque.knee": 110, "range.hip_y": (-120, 20), "mass_mult.foot": 0.8}."""
+    import copy
+    P = copy.deepcopy(DEFAULTS[kind])
+    for k, v in (overrides or {}).items():
+        if "." in k:
+            a, b = k.split(".", 1)
+            if b not in P[a]:
+                raise KeyError(k)
+            P[a][b] = v
+        else:
+            if k not in P:
+                raise KeyError(k)
+            P[k] = v
+    return P
+
+
+def _key(name):
+    return name.replace("right_", "").replace("left_", "")
+
+
+def _humanoid(P):
+    """Shared topology; the numbers of P distinguish Walker3D from Mike."""
+    global DENSITY
+    dens0, DENSITY = DENSITY, P["density"]        # the primitive helpers read the module constant
+    try:
+        return _humanoid_at_density(P)
+    finally:
+        DENSITY = dens0
+
+
+def _humanoid_at_density(P):
+    scale_leg, scale_arm, torso_w, mass_scale, z_extra_head = P["leg_scale"], P["arm_scale"], P["torso_w"], P["mass_scale"], P["head_extra"]
     g = {}          # body -> list of geoms
+    grp = {}        # body -> mass group
     r = np.zeros((NJ, 3))
     # ---- torso (body 0): chest capsule across y, head, upper waist
     g[0] = [
@@ -123,118 +197,101 @@ def _humanoid(scale_leg, scale_arm, torso_w, mass_scale, gains, z_extra_head):
         _sphere([0, 0, 0.19 + z_extra_head], 0.09 + z_extra_head * 0.5),
         _capsule([-0.01, -0.06, -0.12], [-0.01, 0.06, -0.12], 0.06),
     ]
+    grp[0] = "torso"
     # ---- spine: abdomen_z (massless) -> abdomen_y (lwaist) -> abdomen_x (pelvis)
-    r[0] = [-0.01, 0, -0.195]
+    r[0] = [P["spine_r0"][0], 0, P["spine_r0"][1]]
     g[1] = []
     r[1] = [0, 0, 0]
     g[2] = [_capsule([0, -0.06, -0.065], [0, 0.06, -0.065], 0.06)]
-    r[2] = [0, 0, -0.13]
+    grp[2] = "lwaist"
+    r[2] = [0, 0, P["spine_r2"]]
     g[3] = [_capsule([-0.02, -0.07, -0.10], [-0.02, 0.07, -0.10], 0.09)]
+    grp[3] = "pelvis"
     # ---- legs
-    thigh = 0.34 * scale_leg
-    knee_off = thigh + 0.043
-    shin = 0.30 * scale_leg
-    ankle_off = shin + 0.05
+    thigh = P["thigh"] * scale_leg
+    knee_off = thigh + P["knee_gap"]
+    shin = P["shin"] * scale_leg
+    ankle_off = shin + P["ankle_gap"]
+    fc, fh = P["foot_box_c"], P["foot_box_half"]
     for side, j0 in ((-1.0, 3), (1.0, 8)):
-        r[j0] = [0, side * 0.10, -0.14]       # hip_x origin in pelvis link frame
+        r[j0] = [0, side * P["hip_y"], P["hip_z"]]   # hip_x origin in pelvis link frame
         g[j0 + 1] = []
         r[j0 + 1] = [0, 0, 0]                 # hip_z co-located
         g[j0 + 2] = []
         r[j0 + 2] = [0, 0, 0]                 # hip_y co-located -> thigh
-        g[j0 + 3] = [_capsule([0, 0, 0], [0, 0, -thigh], 0.06)]
+        g[j0 + 3] = [_capsule([0, 0, 0], [0, 0, -thigh], P["thigh_radius"])]
+        grp[j0 + 3] = "thigh"
         r[j0 + 3] = [0, 0, -knee_off]         # knee -> shin
-        g[j0 + 4] = [_capsule([0, 0, -0.02], [0, 0, -0.02 - shin], 0.049)]
+        g[j0 + 4] = [_capsule([0, 0, -0.02], [0, 0, -0.02 - shin], P["shin_radius"])]
+        grp[j0 + 4] = "shin"
         r[j0 + 4] = [0, 0, -ankle_off]        # ankle -> foot
-        g[j0 + 5] = [_box([0.04, 0, -0.05], [0.10, 0.05, 0.025])]
+        g[j0 + 5] = [_box([fc[0], 0, fc[1]], list(fh))]
+        grp[j0 + 5] = "foot"
     # ---- arms
-    upper = 0.28 * scale_arm
-    lower = 0.25 * scale_arm
+    upper = P["upper_arm"] * scale_arm
+    lower = P["lower_arm"] * scale_arm
     for side, j0 in ((-1.0, 13), (1.0, 17)):
-        r[j0] = [0, side * (torso_w + 0.10), 0.06]
+        r[j0] = [0, side * (torso_w + P["shoulder_out"]), P["shoulder_z"]]
         g[j0 + 1] = []
         r[j0 + 1] = [0, 0, 0]
         g[j0 + 2] = []
         r[j0 + 2] = [0, 0, 0]
         g[j0 + 3] = [_capsule([0, 0, 0], [0, 0, -upper], 0.04)]
+        grp[j0 + 3] = "upper_arm"
         r[j0 + 3] = [0, 0, -upper]
         g[j0 + 4] = [_capsule([0, 0, 0], [0, 0, -lower], 0.031), _sphere([0, 0, -lower - 0.02], 0.04)]
+        grp[j0 + 4] = "lower_arm"
 
     mass = np.zeros(NB)
     com = np.zeros((NB, 3))
     inertia_o = np.zeros((NB, 3, 3))
     for b in range(NB):
         m, c, Io = _compose(g[b])
-        mass[b] = m * mass_scale
+        f = mass_scale * (P["mass_mult"][grp[b]] if b in grp else 1.0)
+        mass[b] = m * f
         com[b] = c
-        inertia_o[b] = Io * mass_scale
+        inertia_o[b] = Io * f
 
-    #            lo   hi          (degrees, about the +axis of the link frame)
-    rng = np.array([
-        _deg(-45, 45), _deg(-75, 30), _deg(-35, 35),
-        _deg(-25, 5), _deg(-60, 35), _deg(-110, 20), _deg(2, 160), _deg(-50, 50),
-        _deg(-5, 25), _deg(-35, 60), _deg(-110, 20), _deg(2, 160), _deg(-50, 50),
-        _deg(-120, 30), _deg(-60, 60), _deg(-120, 60), _deg(-140, -2),
-        _deg(-30, 120), _deg(-60, 60), _deg(-120, 60), _deg(-140, -2),
-    ])
-    coef = {
-        "abdomen_z": gains["abd"][0], "abdomen_y": gains["abd"][1], "abdomen_x": gains["abd"][2],
-        "hip_x": gains["hip"][0], "hip_z": gains["hip"][1], "hip_y": gains["hip"][2],
-        "knee": gains["knee"], "ankle": gains["ankle"],
-        "shoulder_x": gains["sho"][0], "shoulder_z": gains["sho"][1], "shoulder_y": gains["sho"][2],
-        "elbow": gains["elbow"],
-    }
-    damp = {"abdomen_z": 5, "abdomen_y": 5, "abdomen_x": 5, "hip_x": 5, "hip_z": 5, "hip_y": 5,
-            "knee": 1, "ankle": 1, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 1}
-    stiff = {"abdomen_z": 20, "abdomen_y": 10, "abdomen_x": 10, "hip_x": 10, "hip_z": 10, "hip_y": 20,
-             "knee": 1, "ankle": 0, "shoulder_x": 1, "shoulder_z": 1, "shoulder_y": 1, "elbow": 0}
-    arm = {"abdomen_z": .02, "abdomen_y": .02, "abdomen_x": .02, "hip_x": .01, "hip_z": .01, "hip_y": .01,
-           "knee": .006, "ankle": .004, "shoulder_x": .004, "shoulder_z": .004, "shoulder_y": .004,
-           "elbow": .003}
+    #            lo   hi          (degrees, about the +axis of the link frame); the left side's x / z joints are the mirror image
+    def rng_of(name):
+        lo, hi = P["range"][_key(name)]
+        if name.startswith("left_") and AXIS[JOINT_NAMES.index(name)] != 1:
+            lo, hi = -hi, -lo
+        return _deg(lo, hi)
+    rng = np.array([rng_of(n) for n in JOINT_NAMES])
 
-    def key(name):
-        return name.replace("right_", "").replace("left_", "")
-
-    torque = np.array([coef[key(n)] for n in JOINT_NAMES], float)
-    damping = np.array([damp[key(n)] for n in JOINT_NAMES], float)
-    stiffness = np.array([stiff[key(n)] for n in JOINT_NAMES], float)
-    armature = np.array([arm[key(n)] for n in JOINT_NAMES], float)
-    k_lim = 50.0 * torque           # unilateral limit spring  [N m / rad]
-    d_lim = 0.02 * k_lim            # limit damper (active only in violation) [N m s / rad]
+    torque = np.array([P["torque"][_key(n)] for n in JOINT_NAMES], float)
+    damping = np.array([P["damping"][_key(n)] for n in JOINT_NAMES], float)
+    stiffness = np.array([P["stiffness"][_key(n)] for n in JOINT_NAMES], float)
+    armature = np.array([P["armature"][_key(n)] for n in JOINT_NAMES], float)
+    k_lim = P["k_lim_per_torque"] * torque           # unilateral limit spring  [N m / rad]
+    d_lim = P["d_lim_per_k"] * k_lim                 # limit damper (active only in violation) [N m s / rad]
 
     # nominal pose: slight crouch so reset starts in a balanced, bent-knee stance
     q0 = np.zeros(NJ)
     for j0 in (3, 8):
-        q0[j0 + 2] = np.deg2rad(-12.0)   # hip_y (flexion is negative about +y)
-        q0[j0 + 3] = np.deg2rad(24.0)    # knee
-        q0[j0 + 4] = np.deg2rad(-12.0)   # ankle keeps the sole level
+        q0[j0 + 2] = np.deg2rad(P["q0_deg"]["hip_y"])   # hip_y (flexion is negative about +y)
+        q0[j0 + 3] = np.deg2rad(P["q0_deg"]["knee"])    # knee
+        q0[j0 + 4] = np.deg2rad(P["q0_deg"]["ankle"])   # ankle keeps the sole level
     for j0 in (13, 17):
-        q0[j0 + 3] = np.deg2rad(-20.0)   # elbow inside its range
+        q0[j0 + 3] = np.deg2rad(P["q0_deg"]["elbow"])   # elbow inside its range
 
     # foot sole contact points (foot link frame): 4 corners of the box bottom
-    corners = np.array([[0.14, -0.05, -0.075], [0.14, 0.05, -0.075],
-                        [-0.06, -0.05, -0.075], [-0.06, 0.05, -0.075]])
+    xf, xb, yh, zs = P["sole"]
+    corners = np.array([[xf, -yh, zs], [xf, yh, zs], [xb, -yh, zs], [xb, yh, zs]])
     return dict(mass=mass, com=com, inertia_o=inertia_o, r=r, range=rng, torque=torque,
                 damping=damping, stiffness=stiffness, armature=armature, k_lim=k_lim, d_lim=d_lim,
-                q0=q0, corners=corners)
+                q0=q0, corners=corners, friction=float(P["friction"]))
 
 
-def build(kind):
+def build(kind, overrides=None):
     """kind: 'walker3d' | 'mike' -> dict of float64 numpy arrays + scalars."""
-    if kind == "walker3d":
-        m = _humanoid(1.0, 1.0, 0.07, 1.0,
-                      dict(abd=(60, 80, 60), hip=(80, 60, 100), knee=90, ankle=60,
-                           sho=(60, 60, 50), elbow=60), 0.0)
-    elif kind == "mike":
-        # Mike: stockier body, shorter limbs, stronger legs (own numbers; upstream asset absent)
-        m = _humanoid(0.85, 0.9, 0.11, 1.25,
-                      dict(abd=(80, 100, 80), hip=(100, 80, 130), knee=120, ankle=80,
-                           sho=(60, 60, 50), elbow=60), 0.04)
-    else:
+    if kind not in DEFAULTS:
         raise ValueError("unknown robot kind %r" % (kind,))
+    m = _humanoid(params(kind, overrides))
     m["kind"] = kind
     m["parent"] = np.array(PARENT, np.int32)
     m["axis"] = np.array(AXIS, np.int32)
-    m["friction"] = 0.9
     m["stand_height"] = standing_height(m)
     return m
 

@@ -187,6 +187,8 @@ class PPO:
         if self._static is None:
             self._static = (tuple(torch.empty_like(t) for t in data), torch.zeros_like(idx), torch.zeros(3, device=idx.device))
             refresh = True
+        if self.graph_fallback is not None:        # capture was abandoned once: never retried, straight to the eager step
+            return torch.stack(self._gathered_step(data, idx))
         sdata, sidx, sout = self._static
         if refresh:
             for dst, src in zip(sdata, data):
@@ -455,11 +457,25 @@ def save_checkpoint(ac, path, **meta):
     needed to rebuild the module -- torch.load(path)["state_dict"] -> ActorCritic(...).load_state_dict."""
     sd = {k: v.detach().cpu() for k, v in ac.state_dict().items()}
     torch.save({"state_dict": sd, "num_ensembles": len(ac.critics), "state_dim": ac.actor.state_dim,
-                "action_dim": ac.actor.action_dim, **meta}, path)
+                "action_dim": ac.actor.action_dim, "policy_convention": policy_convention(), **meta}, path)
 
 
-def load_checkpoint(path, device="cpu"):
+def policy_convention():
+    """What a trained policy's inputs and outputs MEAN: the env's ABI version and the per-joint sign of the policy coordinates
+    (docs/PHYSICS.md 2).  ABI 3 -> 4 flipped the sign of the left limbs' x / z joints and of both knees under the same layout, so a
+    file without this stamp (rounds 1-3) or with another one would load silently and drive the robot with flipped joints."""
+    from . import model
+    from ._lib import ABI_VERSION
+    return {"abi_version": int(ABI_VERSION), "policy_sign": [int(s) for s in model.POLICY_SIGN]}
+
+
+def load_checkpoint(path, device="cpu", allow_convention_mismatch=False):
+    """Refuses a file whose policy convention is missing or differs from this build's (INTEGRATION.md "checkpoints")."""
     ck = torch.load(path, map_location="cpu", weights_only=True)
+    have, want = ck.get("policy_convention"), policy_convention()
+    if have != want and not allow_convention_mismatch:
+        raise ValueError("%s was trained under policy convention %r, this build presents %r: its actions and observations would be "
+                         "misread (pass allow_convention_mismatch=True to load it anyway)" % (path, have, want))
     ac = ActorCritic(ck["state_dim"], ck["action_dim"], num_ensembles=ck["num_ensembles"])
     ac.load_state_dict(ck["state_dict"])
     return ac.to(device), ck

@@ -1,7 +1,14 @@
 """The parity rule of the GPU tests: how ONE control step of the HIP path, started from an injected state, is judged
 against the CPU oracle.  TEST INFRASTRUCTURE (imports oracle_lib).
 
-Every env-step is bounded -- none passes on an allowance:
+FROZEN for round 5 (tests/parity_rule.lock holds the SHA-256 of this file; tests/test_parity_rule_frozen.py fails on any edit): the
+constants below were calibrated on rounds 3-4's kernels and amended four times in round 4 after misses, so from here on a miss is
+fixed in the kernel or reported as a miss -- not absorbed by the rule.  Held-out validation: tools/parity_heldout.py.
+
+Every env-step is bounded.  The acceptance region is NOT the plain max(floor, 8 s) alone: an env-step may sit between 1 x and 2 x its
+sensitivity-scaled bound (`beyond`, counted; callers assert <= 2 in 10 000, never a plain step), and a bound above its ceiling is
+counted as `loose` (asserted < 1 %) rather than capped.  Both escape hatches, the alternative-branch matches and the integer
+mismatches excused by an unstable probe are reported by summarize() and by every caller:
 
   integers (next_step_index, counters, RNG counter, contact flags, done, bad_transition, update_terrain): bit-exact;
   observation: |obs_hip - obs_oracle| <= max(1e-4, 8 s)      (1e-4 = the north-star's per-step bound)

@@ -93,6 +93,8 @@ def test_learner_header_symbols_are_exported():
     parameter layout of the Python side equals the library's, and creation fails loudly without a GPU."""
     import torch
     from steppingstone_amd import fused_ppo
+    if not os.path.exists(fused_ppo.LIB_PATH):
+        pytest.skip("opt-in fused learner not built (SS_BUILD_LEARNER=1 python -m steppingstone_amd.build)")
     src = open(os.path.join(ROOT, "include", "steppingstone_learner.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(ssl_[a-z_0-9]+)\s*\(", src)))

@@ -13,6 +13,7 @@ step kernel and rollout kernel.
 The -m "not gpu" half builds the client and checks the duplicate-id arithmetic of the inputs on the oracle."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -20,16 +21,9 @@ import pytest
 import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tests", "host", "first_launch_check.c")
-EXE = os.path.join(ROOT, "tests", "host", "first_launch_check")
 PROCESSES_PER_CASE = 7
-
-
-def build_client():
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(SRC):
-        subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-Wall", SRC, "-o", EXE, "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64",
-                               "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
-    return EXE
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from build_c_client import build_client  # noqa: E402  (tools/build_c_client.py: ROCm root resolved, not hard-coded)
 
 
 def write_inputs(path, kind, n):

@@ -1,16 +1,19 @@
 """GPU parity tests: the HIP path (through the C ABI, via steppingstone_amd.envs) against the CPU oracle on the
 same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
 
-Tolerances (fp32, stated here as required by the task brief; the rule itself is tests/parity_rule.py):
+Tolerances (fp32, stated here as required by the task brief; the rule itself is tests/parity_rule.py -- FROZEN, see its header and
+tests/parity_rule.lock -- and the thresholds every caller asserts are tests/parity_assert.py):
   * integer / index / RNG-driven quantities (next_step_index, counters, rng counter, sampled grid cell, contact flags,
     done, bad_transition, update_terrain): bit-exact;
   * one control step from an identical injected state (4 substeps, different operation order, own sincos / reciprocal):
-    EVERY env-step is bounded by |obs| error <= max(1e-4, 8 s), |rew| error <= max(1e-3, 8 s_rew), where 1e-4 is the
-    north-star's per-step bound and s is the measured first-order response of the fp64 oracle to an 8-ulp error in
-    each of that step's 55 dynamic state inputs (summed); an env-step whose oracle evaluation has a discrete decision
-    within 1e-5 of its threshold must match the oracle re-evaluated on one of the alternative branches (integers
-    exactly).  No env-step passes on an allowance; integer mismatches are accepted nowhere except where the 8-ulp
-    probe itself changes an integer outcome (asserted < 0.1 % of env-steps, measured 0);
+    |obs| error <= max(1e-4, 8 s), |rew| error <= max(1e-4, 8 s_rew), post-step pose <= max(1e-4, 8 s_pose), post-step rates <=
+    max(1e-3, 8 s_vel), where 1e-4 is the north-star's per-step bound and s is the measured first-order response of the fp64 oracle
+    to an 8-ulp error in each of that step's 55 dynamic state inputs (summed).  An env-step whose oracle evaluation has a discrete
+    decision within 1e-5 of its threshold must match the oracle re-evaluated on one of the alternative branches (integers exactly).
+    The rule's escape hatches, all counted and asserted rare by parity_assert.assert_judged: an env-step between 1 x and 2 x its
+    sensitivity-scaled bound (`beyond`, <= 2 in 10 000, never a plain step); a bound above its ceiling (`loose`, < 1 %); an integer
+    mismatch where the 8-ulp probe itself changes an integer outcome (< 0.1 %); at most half of the env-steps on a scaled bound;
+  * launch shapes and kernel variants of the SAME step are compared bitwise (array_equal), never with a tolerance;
   * free-running drift is chaotic (contacts make/break): characterised against the fp64 build, see
     tests/test_gpu_branches.py::test_closed_loop_1000_step_drift.
 """
@@ -95,26 +98,7 @@ def _judged_steps(env_id, kind, n, steps, seed, curriculum=0, on_device_actions=
     return pr.summarize(res)
 
 
-def _assert_judged(R, txt, label):
-    print("%s: %s" % (label, txt))
-    print("   bound quantiles over env-steps 50/90/99/100 %%: %s ; |hip - oracle| quantiles: %s" % (
-        np.array2string(np.quantile(R["tol"], [.5, .9, .99, 1.0]), precision=2), np.array2string(np.quantile(R["e_obs"], [.5, .9, .99, 1.0]), precision=2)))
-    assert R["ok"].all(), "%d env-steps outside their bound" % (~R["ok"]).sum()
-    plain = R["category"] == 0
-    assert plain.mean() > 0.5 and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 8 s <= 1e-4
-    assert R["int_excused"].mean() < 1e-3
-    assert (R["category"] % 2 == 1).mean() < 0.5           # at most half of the env-steps may be held to a sensitivity-scaled bound
-    assert R["loose"].mean() <= max(pr.LOOSE_MAX_FRACTION, 2.0 / R["loose"].size)      # bounds beyond their ceilings stay rare
-    # the tail of err / bound: at most 2 in 10 000 env-steps (1 in a small test) between 1 x and 2 x their bound, none of them a plain
-    # step (asserted above), and the bulk far inside: 99.9 % of env-steps below half their bound (measured 0.10 - 0.13)
-    assert R["beyond"].sum() <= max(1, int(pr.BEYOND_MAX_FRACTION * R["beyond"].size)), "%d env-steps beyond their bound" % R["beyond"].sum()
-    assert np.quantile(R["matched_e"] / R["tol"], 0.999) < 0.5
-    # all env-steps, against the oracle as it ran: 99 % within the north-star's 1e-4 (measured: 99 % within 2e-5), at most 0.5 % beyond it
-    assert np.quantile(R["e_obs"], 0.99) < 1e-4 and (R["e_obs"] > 1e-4).mean() < 5e-3
-    # ... and against the fp64 evaluation the kernel is no noisier than the CPU's own fp32 build (which also leaves 1e-4 on ~0.16 %)
-    far_hip, far_cpu = int((R["e_hip_o64"] > 1e-4).sum()), int((R["e_o32_o64"] > 1e-4).sum())
-    print("   env-steps farther than 1e-4 from the fp64 oracle: HIP kernel %d, fp32 CPU oracle %d (of %d)" % (far_hip, far_cpu, R["ok"].size))
-    assert far_hip <= 1.5 * far_cpu + 8
+from parity_assert import assert_judged as _assert_judged  # noqa: E402  (one set of thresholds for tests, smoke and the held-out tool)
 
 
 def _judged_step(J, g, st, a):
@@ -271,20 +255,23 @@ def test_full_size_rollout_properties(env_id):
 
 
 def test_rollout_matches_step_with_explicit_actions():
-    n = 128
-    a_env = gpu_env("Walker3DStepperEnv-v0", n, seed=4)
-    b_env = gpu_env("Walker3DStepperEnv-v0", n, seed=4)
-    a_env.reset()
-    b_env.reset()
-    for t in range(5):
-        oa, ra, da = a_env.rollout_random(1, t0=t)
-        ob, rb, db, _ = b_env.step(b_env.random_actions(t))
-        # two template instantiations of the same kernel (on-device vs explicit actions): identical actions,
-        # fp contraction may differ in the last bits
-        assert np.abs(oa.cpu().numpy() - ob).max() < 1e-4
-        assert np.abs(ra.cpu().numpy().astype(np.float64) - rb).max() < 1e-3
-    a_env.close()
-    b_env.close()
+    """ss_step with an explicit action array (what a policy in the loop calls) and ss_rollout_random(1) (the benchmarked kernel's
+    instantiation, which draws the same Philox actions on the device) are the same step: bitwise, both robots, batch sizes that select
+    each kernel variant by themselves (DESIGN.md section 2 item 1 states bit-identity across launch shapes as a product requirement)."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    for env_id, n in (("Walker3DStepperEnv-v0", 128), ("MikeStepperEnv-v0", 200), ("Walker3DStepperEnv-v0", 4096)):
+        a_env = SteppingStoneVecEnv(env_id, n, seed=4, device="cuda:0", return_numpy=False)
+        b_env = SteppingStoneVecEnv(env_id, n, seed=4, device="cuda:0", return_numpy=False)
+        for e in (a_env, b_env):
+            e.update_curriculum(5)
+            e.reset()
+        for t in range(40):
+            oa, ra, da = a_env.rollout_random(1, t0=t)
+            ob, rb, db, _ = b_env.step(b_env.random_actions(t))
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (env_id, n, t)
+        assert torch.equal(a_env.get_state(), b_env.get_state())
+        a_env.close()
+        b_env.close()
 
 
 def test_single_env_facade_and_errors():
@@ -435,27 +422,39 @@ def test_ppo_graph_replay_matches_eager():
     # 8 x lr = 2.4e-3 they can have moved, the last minibatch's losses to 1 %
     assert torch.allclose(finals[0][0], finals[1][0], atol=5e-4), float((finals[0][0] - finals[1][0]).abs().max())
     assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-2, atol=1e-4)
-    # rollout: three collector calls (eager warm-up, capture+replay, replay) against three eager collects, same seeds
-    stores = []
-    for graphed in (False, True):
+    # rollout: three collector calls (eager warm-up, capture + replay, replay).  The sampling noise of a replayed graph comes from other
+    # generator offsets than the eager loop's, so the captured rollout is checked against what it must be, not against another noise
+    # stream: (a) the whole run repeated from the same seeds reproduces every stored tensor bit for bit (replay determinism);
+    # (b) the ACTIONS the graphed run stored, fed step by step to a fresh env from the same reset through plain ss_step launches,
+    # reproduce the stored observations, rewards and masks bit for bit -- i.e. the captured graph really is policy -> env -> storage.
+    def graphed_run():
         torch.manual_seed(9)
         envs = SteppingStoneVecEnv("MikeStepperEnv-v0", 256, seed=4, device=dev, return_numpy=False)
         ac = ppo.ActorCritic().to(dev)
         roll = ppo.Rollouts(8, 256, dev)
         roll.obs[0].copy_(envs.reset())
         col = ppo.GraphedCollector(envs, ac, roll, 8)
+        chunks = []
         for _ in range(3):
-            if graphed:
-                st = col().clone()
-            else:
-                st = torch.zeros(2, device=dev)
-                ppo.collect(envs, ac, roll, 8, ep_stats=st)
+            col()
+            chunks.append((roll.obs.clone(), roll.actions.clone(), roll.rewards.clone(), roll.masks.clone(), roll.logp.clone(), roll.value_preds.clone()))
             roll.after_update()
-        stores.append((roll.obs.clone(), roll.rewards.clone(), roll.masks.clone()))
+        assert col.graph is not None
         envs.close()
-    # the sampling noise differs between the eager and the replayed generator offsets, so compare what does not depend
-    # on it: shapes, finiteness and the first observation row (reset state); then require exact replay determinism
-    assert stores[0][0].shape == stores[1][0].shape and torch.isfinite(stores[1][0]).all() and torch.isfinite(stores[1][1]).all()
+        return chunks
+    run1, run2 = graphed_run(), graphed_run()
+    for c1, c2 in zip(run1, run2):
+        assert all(torch.equal(a, b) for a, b in zip(c1, c2)), "graph replay is not deterministic"
+    envs = SteppingStoneVecEnv("MikeStepperEnv-v0", 256, seed=4, device=dev, return_numpy=False)
+    obs = envs.reset()
+    for obs_c, act_c, rew_c, mask_c, _, _ in run1:
+        assert torch.equal(obs_c[0], obs)
+        for t in range(8):
+            obs, rew, done, _ = envs.step(act_c[t])
+            assert torch.equal(obs, obs_c[t + 1]) and torch.equal(rew, rew_c[t, :, 0]), t
+            assert torch.equal(1.0 - done.to(torch.float32), mask_c[t + 1, :, 0])
+    envs.close()
+    assert all(torch.isfinite(c[4]).all() and torch.isfinite(c[5][:-1]).all() for c in run1)      # log-probabilities and values were stored
 
 
 def test_large_batch_is_a_union_of_small_ones():

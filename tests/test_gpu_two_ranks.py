@@ -2,7 +2,7 @@
 GPU per rank).  What a multi-GPU run does, with the real HIP kernels under it:
   * env sharding: each rank steps its block of envs (global env ids key every random stream), the packed blocks are all-gathered
     per step and per chunk of K steps -- every rank ends up with exactly what ONE process stepping all envs produces, bit for bit;
-  * data-parallel PPO with the fused learner: ssl_grad, one all-reduce of the flat gradient, ssl_apply -- replicas stay identical.
+  * data-parallel PPO (the default torch learner: gradients all-reduced between backward and Adam) -- replicas stay identical.
 `pytest -m gpu`."""
 import os
 import sys
@@ -80,14 +80,14 @@ def _train_worker(rank, port, ret):
     from steppingstone_amd import ppo
     from steppingstone_amd.envs import SteppingStoneVecEnv
     envs = SteppingStoneVecEnv("Walker3DStepperEnv-v0", 256, seed=8, device="cuda:0", return_numpy=False, env_id_offset=rank * 256)
-    ac, hist = ppo.train(envs, num_updates=3, num_steps=8, ppo_epoch=2, mini_batch_size=512, log=None, learner="fused")
+    ac, hist = ppo.train(envs, num_updates=3, num_steps=8, ppo_epoch=2, mini_batch_size=512, log=None, learner="torch")
     ret[rank] = (torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).cpu().numpy(),
                  [(h["value_loss"], h["action_loss"]) for h in hist], hist[-1]["total_num_steps"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_fused_data_parallel_training_keeps_the_replicas_identical():
+def test_data_parallel_training_keeps_the_replicas_identical():
     import torch.multiprocessing as mp
     port = 37500 + os.getpid() % 2000
     with mp.Manager() as mgr:

@@ -1,0 +1,20 @@
+"""The parity rule is frozen for the round: any edit to tests/parity_rule.py -- constants, search depth, tail factor,
+a docstring -- changes its SHA-256 and fails here.  Re-locking is a deliberate, visible act: `sha256sum tests/parity_rule.py >
+tests/parity_rule.lock` in a commit of its own whose message says why."""
+import hashlib
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_parity_rule_is_the_locked_one():
+    want = open(os.path.join(HERE, "parity_rule.lock")).read().split()[0]
+    have = hashlib.sha256(open(os.path.join(HERE, "parity_rule.py"), "rb").read()).hexdigest()
+    assert have == want, "tests/parity_rule.py was edited after it was frozen"
+
+
+def test_frozen_constants_are_the_round_4_values():
+    import parity_rule as pr
+    assert (pr.OBS_TOL, pr.REW_TOL, pr.NEAR_TOL, pr.POSE_TOL, pr.VEL_TOL) == (1e-4, 1e-4, 1e-5, 1e-4, 1e-3)
+    assert (pr.OBS_CEIL, pr.POSE_CEIL, pr.VEL_CEIL, pr.REW_CEIL, pr.LOOSE_MAX_FRACTION) == (5e-3, 5e-3, 5e-2, 5e-2, 1e-2)
+    assert (pr.ULPS, pr.SENS_FACTOR, pr.TAIL_FACTOR, pr.BEYOND_MAX_FRACTION, pr.MAX_DEPTH, pr.MAX_ALTERNATIVES) == (8.0, 8.0, 2.0, 2e-4, 3, 24)

@@ -178,3 +178,19 @@ def test_legacy_reader_rejects_other_files(tmp_path):
         q.write_bytes(raw[: len(raw) - 1000])
         with pytest.raises(Exception):
             lc.read_legacy(str(q))
+    # a crafted file whose HEADER records name a global (the classic os.system pickle) is refused before anything runs
+    import pickle
+
+    class Boom:
+        def __reduce__(self):
+            return (os.mkdir, (str(tmp_path / "pwned"),))
+    for pos in (1, 2):
+        recs = [lc._MAGIC, 1001, {"little_endian": True}]
+        recs[pos] = Boom()
+        evil = tmp_path / ("evil%d.pt" % pos)
+        with open(evil, "wb") as f:
+            for r in recs:
+                pickle.dump(r, f, protocol=2)
+        with pytest.raises(pickle.UnpicklingError, match="refused"):
+            lc.read_legacy(str(evil))
+        assert not (tmp_path / "pwned").exists()

@@ -7,6 +7,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle_backend import OracleBackend
@@ -91,6 +92,19 @@ def test_training_loop_with_threshold_sampler_logs_and_checkpoints(tmp_path):
     for (k, a), (_, b) in zip(ac.state_dict().items(), ac2.state_dict().items()):
         assert torch.equal(a, b), k
     assert ck["update"] == 3 and ck["num_ensembles"] == 2
+    # the policy convention (ABI version + per-joint signs) travels with the file; a file without it, or with the rounds-1..3
+    # convention (same layout, left x / z joints and knees of the other sign), is refused instead of driving flipped joints
+    assert ck["policy_convention"] == ppo.policy_convention() and ck["policy_convention"]["abi_version"] >= 4
+    old = dict(ck)
+    old.pop("policy_convention")
+    torch.save(old, str(tmp_path / "ckpt" / "unstamped.pt"))
+    with pytest.raises(ValueError, match="policy convention"):
+        ppo.load_checkpoint(str(tmp_path / "ckpt" / "unstamped.pt"))
+    old["policy_convention"] = {"abi_version": 3, "policy_sign": [1] * 21}
+    torch.save(old, str(tmp_path / "ckpt" / "abi3.pt"))
+    with pytest.raises(ValueError, match="policy convention"):
+        ppo.load_checkpoint(str(tmp_path / "ckpt" / "abi3.pt"))
+    ppo.load_checkpoint(str(tmp_path / "ckpt" / "abi3.pt"), allow_convention_mismatch=True)
 
 
 def test_adaptive_sampler_and_specialist_switches():

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Joint system identification of the robot specification against the reference's SHIPPED policies.
+
+INFORMATIONAL, this container only (the policies live under /root/reference, the env is the CPU oracle); never a parity claim.
+The one reference-held signal about the physics: `playground/enjoy.py:143-235` loads `playground/models/*_latest.pt` and walks the
+course; in our env the same deterministic actors fall after 1-2 stones.  Single-parameter scans (tools/policy_physics_scan.py) moved
+that by +-15 steps.  This tool searches ALL free numbers of steppingstone_amd/model.py jointly with a (mu/mu_w, lambda)-CMA-ES:
+
+  per link group masses (8) | segment lengths, hip / spine offsets, sole geometry (14) | torque limits per joint type (12) |
+  passive damping / stiffness / armature scales, limit spring / damper (5) | joint ranges lo / hi per type (24: they scale 21 of the
+  60 observation inputs) | nominal pose (4) | friction (1)
+
+and maximises, over 64 envs on flat terrain from the reset distribution, the mean number of stones the deterministic shipped actor
+reaches (+ a small credit for staying up).  Candidates are evaluated in worker processes on private model tables handed to the
+oracle through sso_debug_set_model (the compiled-in specification is untouched).
+
+  python tools/sysid_policy.py --kind walker3d --generations 400 --out profiles/r05_sysid_walker3d
+  python tools/sysid_policy.py --kind walker3d --evaluate profiles/r05_sysid_walker3d_best.json      # re-score a result on other seeds / terrain
+"""
+import argparse
+import ctypes as C
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
+MODELS = "/root/reference/playground/models/"
+POLICY = {"walker3d": "mocca_envs:Walker3DStepperEnv-v0_latest.pt", "mike": "mocca_envs:MikeStepperEnv-v0_latest.pt"}
+
+# ------------------------------------------------------------------------------------------------ the search space
+# (name, kind of coordinate, initial std in search units, lo, hi).  "log": multiplier exp(x) on the default; "add": default + x.
+LOGM = lambda name, std=0.20, lo=-1.4, hi=1.4: (name, "log", std, lo, hi)      # noqa: E731
+ADD = lambda name, std, lo, hi: (name, "add", std, lo, hi)                      # noqa: E731
+
+
+def space():
+    from steppingstone_amd import model
+    S = []
+    for g in model.MASS_GROUPS:
+        S.append(LOGM("mass_mult." + g))
+    for k in ("thigh", "shin", "upper_arm", "lower_arm", "hip_y", "torso_w"):
+        S.append(LOGM(k, 0.08, -0.5, 0.5))
+    S += [ADD("hip_z", 0.02, -0.10, 0.10), ADD("spine_r2", 0.02, -0.08, 0.08), ADD("spine_r0.z", 0.02, -0.10, 0.10),
+          ADD("knee_gap", 0.01, -0.04, 0.05), ADD("ankle_gap", 0.01, -0.04, 0.05),
+          ADD("sole.front", 0.02, -0.08, 0.10), ADD("sole.back", 0.02, -0.08, 0.06), ADD("sole.half_width", 0.01, -0.03, 0.05),
+          ADD("sole.z", 0.01, -0.04, 0.05)]
+    for t in model.JOINT_TYPES:
+        S.append(LOGM("torque." + t, 0.20, -1.6, 1.6))
+    S += [LOGM("scale.damping", 0.5, -5.0, 2.0), LOGM("scale.stiffness", 0.5, -5.0, 2.0), LOGM("scale.armature", 0.5, -4.0, 3.0),
+          LOGM("k_lim_per_torque", 0.4, -2.5, 2.0), LOGM("d_lim_per_k", 0.4, -2.5, 2.0)]
+    for t in model.JOINT_TYPES:
+        S += [ADD("range_lo." + t, 6.0, -40.0, 40.0), ADD("range_hi." + t, 6.0, -40.0, 40.0)]
+    S += [ADD("q0_deg.hip_y", 4.0, -25.0, 25.0), ADD("q0_deg.knee", 6.0, -22.0, 40.0), ADD("q0_deg.ankle", 4.0, -25.0, 25.0),
+          ADD("q0_deg.elbow", 8.0, -60.0, 18.0)]
+    S.append(LOGM("friction", 0.15, -0.9, 0.8))
+    return S
+
+
+def overrides_of(kind, x, S):
+    """search vector -> the `overrides` dict of steppingstone_amd.model.build"""
+    from steppingstone_amd import model
+    D = model.DEFAULTS[kind]
+    ov, rng = {}, {t: list(D["range"][t]) for t in model.JOINT_TYPES}
+    sole = list(D["sole"])
+    r0 = list(D["spine_r0"])
+    for (name, how, _, lo, hi), v in zip(S, np.clip(x, [s[3] for s in S], [s[4] for s in S])):
+        if name.startswith("scale."):
+            key = name.split(".")[1]
+            for t in model.JOINT_TYPES:
+                ov["%s.%s" % (key, t)] = D[key][t] * float(np.exp(v))
+        elif name.startswith("range_lo."):
+            rng[name.split(".")[1]][0] += float(v)
+        elif name.startswith("range_hi."):
+            rng[name.split(".")[1]][1] += float(v)
+        elif name.startswith("sole."):
+            i = {"front": 0, "back": 1, "half_width": 2, "z": 3}[name.split(".")[1]]
+            sole[i] += float(v)
+        elif name == "spine_r0.z":
+            r0[1] += float(v)
+        else:
+            if "." in name:
+                a, b = name.split(".", 1)
+                d0 = D[a][b]
+            else:
+                d0 = D[name]
+            ov[name] = d0 * float(np.exp(v)) if how == "log" else d0 + float(v)
+    for t in model.JOINT_TYPES:
+        lo, hi = rng[t]
+        if hi - lo < 10.0:                         # keep a joint a joint
+            mid = 0.5 * (lo + hi)
+            lo, hi = mid - 5.0, mid + 5.0
+        ov["range." + t] = (lo, hi)
+    sole[2] = max(sole[2], 0.015)
+    sole[0] = max(sole[0], sole[1] + 0.04)
+    ov["sole"] = tuple(sole)
+    ov["spine_r0"] = tuple(r0)
+    return ov
+
+
+# ------------------------------------------------------------------------------------------------ one evaluation (worker side)
+_W = {}
+
+
+class SsoModel(C.Structure):
+    _fields_ = [("mass", C.c_float * 22), ("com", C.c_float * 66), ("inertia", C.c_float * 132), ("r", C.c_float * 63), ("lo", C.c_float * 21),
+                ("hi", C.c_float * 21), ("torque", C.c_float * 21), ("damping", C.c_float * 21), ("stiffness", C.c_float * 21),
+                ("armature", C.c_float * 21), ("klim", C.c_float * 21), ("dlim", C.c_float * 21), ("q0", C.c_float * 21),
+                ("corners", C.c_float * 12), ("friction", C.c_float), ("stand_height", C.c_float)]
+
+
+def pack_model(m):
+    import gen_model_tables as gen
+    sm = SsoModel()
+    for name, shape, vals in gen.fields(m):
+        flat = np.asarray(vals, np.float32).reshape(-1)
+        getattr(sm, name)[:] = flat.tolist()
+    sm.friction = float(m["friction"])
+    sm.stand_height = float(m["stand_height"])
+    return sm
+
+
+def _init_worker(kind):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch
+    torch.set_num_threads(1)
+    import oracle_lib as ol
+    from steppingstone_amd.legacy_checkpoint import load_reference_checkpoint
+    _W["ol"] = ol
+    _W["lib"] = ol.load("f32")
+    _W["lib"].sso_debug_set_model.argtypes = [C.c_int, C.c_void_p]
+    assert _W["lib"].sso_model_size() == C.sizeof(SsoModel), "sso_model layout changed"
+    _W["actor"] = load_reference_checkpoint(MODELS + POLICY[kind]).actor
+    _W["kind"] = kind
+    _W["torch"] = torch
+
+
+def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
+    """deterministic shipped actor in the oracle with model overrides `ov`: first episode of each of n envs"""
+    from steppingstone_amd import model
+    ol, lib, torch, actor = _W["ol"], _W["lib"], _W["torch"], _W["actor"]
+    try:
+        m = model.build(kind, ov)
+    except Exception:
+        return (-1.0, {}) if detail else -1.0
+    sm = pack_model(m)
+    lib.sso_debug_set_model(ol.KIND[kind], C.byref(sm))
+    o = ol.OracleEnv(kind, n, seed=seed)
+    lib.sso_debug_set_model(ol.KIND[kind], None)        # the env keeps its pointer to a static copy; later envs are not affected
+    if curriculum:
+        o.set_curriculum(curriculum)
+    obs = o.reset()
+    alive = np.ones(n, bool)
+    reached = np.ones(n)
+    length = np.zeros(n)
+    for t in range(steps):
+        with torch.no_grad():
+            a = actor(torch.from_numpy(obs)).numpy()
+        obs, _, d, info = o.step(a.astype(np.float32))
+        fin = alive & (d != 0)
+        reached[fin] = info["steps_reached"][fin]
+        length[fin] = info["ep_len"][fin]
+        alive &= ~fin
+        if not alive.any():
+            break
+    if alive.any():
+        st = o.get_state()
+        reached[alive] = st[alive, ol.S_N]
+        length[alive] = st[alive, ol.S_ELAPSED]
+    o.close()
+    # stones reached beyond the start stone (n starts at 1), a small credit for time on the feet
+    score = float(np.mean(reached - 1.0) + 0.004 * np.mean(length))
+    if detail:
+        return score, dict(mean_stones=float(np.mean(reached - 1.0)), median_stones=float(np.median(reached - 1.0)),
+                           max_stones=float(np.max(reached - 1.0)), mean_steps=float(np.mean(length)),
+                           frac_5_stones=float(np.mean(reached - 1.0 >= 5)), total_mass=float(m["mass"].sum()), stand_height=float(m["stand_height"]))
+    return score
+
+
+def _eval(args):
+    x, S = args
+    return rollout(_W["kind"], overrides_of(_W["kind"], x, S))
+
+
+# ------------------------------------------------------------------------------------------------ CMA-ES (Hansen, "The CMA evolution strategy: a tutorial")
+class CMA:
+    def __init__(self, x0, sigma0, popsize, seed=0):
+        n = len(x0)
+        self.n, self.mean, self.sigma, self.lam = n, np.array(x0, float), float(sigma0), int(popsize)
+        self.mu = self.lam // 2
+        w = np.log(self.mu + 0.5) - np.log(np.arange(1, self.mu + 1))
+        self.w = w / w.sum()
+        self.mueff = 1.0 / np.sum(self.w ** 2)
+        self.cc = (4 + self.mueff / n) / (n + 4 + 2 * self.mueff / n)
+        self.cs = (self.mueff + 2) / (n + self.mueff + 5)
+        self.c1 = 2 / ((n + 1.3) ** 2 + self.mueff)
+        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((n + 2) ** 2 + self.mueff))
+        self.damps = 1 + 2 * max(0, np.sqrt((self.mueff - 1) / (n + 1)) - 1) + self.cs
+        self.pc, self.ps = np.zeros(n), np.zeros(n)
+        self.C = np.eye(n)
+        self.B, self.D = np.eye(n), np.ones(n)
+        self.chiN = np.sqrt(n) * (1 - 1 / (4 * n) + 1 / (21 * n * n))
+        self.rng = np.random.default_rng(seed)
+        self.gen = 0
+
+    def ask(self):
+        self.z = self.rng.standard_normal((self.lam, self.n))
+        self.y = (self.z * self.D) @ self.B.T
+        return self.mean + self.sigma * self.y
+
+    def tell(self, fitness):          # maximisation
+        order = np.argsort(-np.asarray(fitness))[:self.mu]
+        yw = self.w @ self.y[order]
+        self.mean = self.mean + self.sigma * yw
+        invsqrt = (self.B / self.D) @ self.B.T
+        self.ps = (1 - self.cs) * self.ps + np.sqrt(self.cs * (2 - self.cs) * self.mueff) * (invsqrt @ yw)
+        self.gen += 1
+        hsig = np.linalg.norm(self.ps) / np.sqrt(1 - (1 - self.cs) ** (2 * self.gen)) / self.chiN < 1.4 + 2 / (self.n + 1)
+        self.pc = (1 - self.cc) * self.pc + hsig * np.sqrt(self.cc * (2 - self.cc) * self.mueff) * yw
+        ys = self.y[order]
+        self.C = ((1 - self.c1 - self.cmu) * self.C + self.c1 * (np.outer(self.pc, self.pc) + (1 - hsig) * self.cc * (2 - self.cc) * self.C)
+                  + self.cmu * (ys.T * self.w) @ ys)
+        self.sigma *= np.exp((self.cs / self.damps) * (np.linalg.norm(self.ps) / self.chiN - 1))
+        self.sigma = float(min(self.sigma, 3.0))
+        if self.gen % max(1, int(1 / (10 * self.n * (self.c1 + self.cmu)))) == 0:
+            self.C = np.triu(self.C) + np.triu(self.C, 1).T
+            d, B = np.linalg.eigh(self.C)
+            self.D, self.B = np.sqrt(np.maximum(d, 1e-20)), B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="walker3d")
+    ap.add_argument("--generations", type=int, default=300)
+    ap.add_argument("--popsize", type=int, default=32)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--evaluate", default="", help="re-score a *_best.json on held-out seeds and on curriculum-5 terrain")
+    ap.add_argument("--resume", default="", help="start from the x of a *_best.json")
+    ap.add_argument("--hours", type=float, default=0.0, help="stop after this much wall-clock time (0: by generations)")
+    args = ap.parse_args()
+    S = space()
+    names = [s[0] for s in S]
+    std = np.array([s[2] for s in S])
+    if args.evaluate:
+        _init_worker(args.kind)
+        best = json.load(open(args.evaluate))
+        x = np.array([best["x"][n] for n in names])
+        for label, ov in (("specification as it is", {}), ("identified model", overrides_of(args.kind, x * std, S))):
+            for cur, seed in ((0, 9), (0, 1234), (0, 777), (5, 1234)):
+                sc, d = rollout(args.kind, ov, n=128, steps=800, seed=seed, curriculum=cur, detail=True)
+                print("%-24s curriculum %d seed %4d: %s" % (label, cur, seed, json.dumps(d)))
+        return
+    out = args.out or os.path.join(ROOT, "gpurun_out", "sysid_%s" % args.kind)
+    pool = mp.get_context("fork").Pool(args.workers, initializer=_init_worker, initargs=(args.kind,))
+    # the search runs in units of each coordinate's own std: x_scaled = x / std, isotropic start
+    x0 = np.zeros(len(S))
+    if args.resume:
+        b = json.load(open(args.resume))
+        x0 = np.array([b["x"].get(n, 0.0) for n in names])
+    es = CMA(x0, 0.5 if args.resume else 1.0, args.popsize, seed=args.seed)
+    base = pool.map(_eval, [(np.zeros(len(S)), S)])[0]
+    print("# %s: %d parameters, population %d, %d workers; score = mean stones beyond the start + 0.004 x mean steps; the specification as it is: %.3f"
+          % (args.kind, len(S), args.popsize, args.workers, base), flush=True)
+    best_f, best_x, t0 = base, np.zeros(len(S)), time.time()
+    log = open(out + "_log.txt", "a")
+    for g in range(args.generations):
+        X = es.ask()
+        F = pool.map(_eval, [(x * std, S) for x in X])
+        es.tell(F)
+        i = int(np.argmax(F))
+        if F[i] > best_f:
+            best_f, best_x = float(F[i]), X[i].copy()
+            json.dump({"kind": args.kind, "score": best_f, "generation": g, "x": {n: float(v) for n, v in zip(names, best_x)},
+                       "overrides": {k: (list(v) if isinstance(v, tuple) else v) for k, v in overrides_of(args.kind, best_x * std, S).items()}},
+                      open(out + "_best.json", "w"), indent=1)
+        line = "gen %4d  best %.3f  gen-best %.3f  gen-median %.3f  mean-point %.3f  sigma %.3f  %.0f s" % (
+            g, best_f, F[i], float(np.median(F)), pool.map(_eval, [(es.mean * std, S)])[0] if g % 10 == 0 else float("nan"), es.sigma, time.time() - t0)
+        print(line, flush=True)
+        log.write(line + "\n")
+        log.flush()
+        if args.hours and time.time() - t0 > 3600 * args.hours:
+            break
+    pool.close()
+
+
+if __name__ == "__main__":
+    main()
