@@ -47,8 +47,8 @@ typedef SSO_REAL real;
 #define DT_CTRL ((real)(1.0 / 60.0))
 #define GRAV ((real)9.8)
 #define STONE_R ((real)0.25)
-#define PGS_ITERS 8
-#define PGS_WARM 0
+#define PGS_ITERS 5   /* PHYSICS.md 3.4 (Bullet's numSolverIterations = 5); rounds 1-4: 8 */
+#define PGS_WARM 1    /* warm start from the previous substep of the same control step; rounds 1-4: none */
 #define ERP ((real)0.2)
 #define SLOP ((real)0.001)
 #define VCORR_MAX ((real)2.0)
@@ -1034,16 +1034,19 @@ void sso_debug_substeps(sso_env* E, int e, const real* tau_m, int n, int* flags4
   flags4[2] = fr.foot_on_target[0]; flags4[3] = fr.foot_on_target[1];
 }
 /* ONE substep of env e with fixed motor torques (state advanced), with the contact stage's intermediate quantities
- * copied to *tap (layout: contact_tap above, mirrored by tests/oracle_lib.py) */
-void sso_debug_contact(sso_env* E, int e, const real* tau_m, contact_tap* tap) {
+ * copied to *tap (layout: contact_tap above, mirrored by tests/oracle_lib.py).  `prior` substeps of the same control step run
+ * before it (untapped), so that the tapped one is warm-started from them (prior = 0: the cold first substep of a step). */
+void sso_debug_contact_after(sso_env* E, int e, const real* tau_m, int prior, contact_tap* tap) {
   foot_report fr;
   warm_state ws;
   memset(&fr, 0, sizeof fr);
   for (int k = 0; k < 8; ++k) ws.stone[k] = -1;
+  for (int k = 0; k < prior; ++k) substep(E->M, &E->e[e], tau_m, &fr, &ws);
   g_tap = tap;
   substep(E->M, &E->e[e], tau_m, &fr, &ws);
   g_tap = 0;
 }
+void sso_debug_contact(sso_env* E, int e, const real* tau_m, contact_tap* tap) { sso_debug_contact_after(E, e, tau_m, 0, tap); }
 int sso_tap_size(void) { return (int)sizeof(contact_tap); }
 /* world position of every body (22 x 3) and rotation (22 x 9) for FK checks */
 void sso_debug_fk(int kind, const real* packed, real* pos, real* rot) {

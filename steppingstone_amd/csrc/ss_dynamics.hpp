@@ -30,10 +30,16 @@ constexpr float kH = 1.0f / 240.0f;
 constexpr float kDt = 1.0f / 60.0f;
 constexpr float kGrav = 9.8f;
 constexpr float kStoneR2 = 0.25f * 0.25f;
+// PHYSICS.md 3.4: 5 sweeps, warm-started from the previous substep of the same control step (Bullet's
+// numSolverIterations = 5 with warm starting; rounds 1-4 ran 8 cold sweeps -- DESIGN.md section 5.1 has the measured trade)
 #ifndef SS_PGS_ITERS
-#define SS_PGS_ITERS 8
+#define SS_PGS_ITERS 5
+#endif
+#ifndef SS_PGS_WARM
+#define SS_PGS_WARM 1
 #endif
 constexpr int kPgsIters = SS_PGS_ITERS;
+constexpr bool kPgsWarm = SS_PGS_WARM != 0;
 constexpr float kErp = 0.2f;
 constexpr float kSlop = 0.001f;
 constexpr float kVcorrMax = 2.0f;
@@ -68,9 +74,18 @@ static_assert(kLdsSlots + kHandSlots <= 80, "two helper-variant workgroups must 
 static_assert(kHandRows + 40 <= kHandJc + 8 * 9, "rows fit the leg records' place");
 constexpr int kHandBase = kLdsSlots * kWave * 4;   // in floats
 constexpr int NH = 12;                 // joints per half
-enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_QDF = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
-       S_END = 79 };
+enum { S_ACT = 0, S_Q = 12, S_QD = 24, S_WLAM = 36, S_POS = 48, S_QUAT = 51, S_VW = 55, S_VV = 58, S_STP = 61, S_STN = 70,
+       S_WKEY = 79, S_END = 80 };
+// S_WLAM / S_WKEY: the warm-start impulses (4 corners x 3) and their key, for the variants whose registers are full (below);
+// rounds 1-2 kept the free joint velocities there, they have lived in registers since
 static_assert(S_END <= (kLdsSlots - kSlotsA) * 4, "LDS scalar region overflow");
+// Where the warm-start impulses live between the substeps of a control step: in registers where there is room (three helper
+// wavefronts: 192 - 205 of 256 AGPRs), in the lane's LDS scalars otherwise (the plain and the one-helper rollout kernels sit at
+// 252 - 255 AGPRs and would spill 20 - 40 B per lane; 13 ds_write + 13 ds_read per substep instead).  Values are the same either way.
+#ifndef SS_WARM_LDS_BELOW
+#define SS_WARM_LDS_BELOW 3
+#endif
+constexpr bool warm_in_lds(int helpers) { return helpers < SS_WARM_LDS_BELOW; }
 
 // the half-tree: global (right-side) joint ids, spine first
 constexpr int kHalf[NH] = {0, 1, 2, 3, 4, 5, 6, 7, 13, 14, 15, 16};
@@ -165,6 +180,16 @@ struct FootReport {   // this lane's foot
   int on_target;      // touches stone n (slot 1)
   float sole[3];      // sole centre, this lane's world
 };
+
+struct Warm {      // this lane's foot: the contact impulses at the end of the previous substep of this control step
+  float lam[4][3];
+  int key;          // bit k: corner k was in contact; bits 4 + 2k, 5 + 2k: on which stone slot (key = 0: nothing to start from)
+};
+SSD void warm_clear(Warm& w) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w.lam[k][0] = w.lam[k][1] = w.lam[k][2] = 0.f;
+  w.key = 0;
+}
 
 struct JRec {      // what the ABA leaves behind per joint
   float cs, sn, Uw[3], Uv[3], Dinv, u;
@@ -764,7 +789,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
 // ---------------------------------------------------------------------------------------------------------------
 // State (q, qd, base pose/twist), stones and clipped actions of THIS lane's world live in LDS (region B).
 template <class Model, int HELPERS = 0>
-SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
+SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& wm) {
   constexpr float h = kH;
   JointCache jc;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1200,6 +1225,28 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
   };
   auto solve = [&]() {              // y = Lambda w, PGS, response of the whole tree
       float ul[NH];
+      float wlam_prev[4][3];           // the previous substep's impulses
+      int wkey_prev = 0;
+      auto load_warm = [&]() {
+        if constexpr (kPgsWarm) {
+          if constexpr (warm_in_lds(HELPERS)) {
+            wkey_prev = __builtin_bit_cast(int, L.s(S_WKEY));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int d = 0; d < 3; ++d) wlam_prev[k][d] = L.s(S_WLAM + 3 * k + d);
+          } else {
+            wkey_prev = wm.key;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+              for (int d = 0; d < 3; ++d) wlam_prev[k][d] = wm.lam[k][d];
+          }
+        }
+      };
+      // with helper wavefronts the loads are issued here and their LDS latency hides behind the rows; the plain variant has no
+      // register to hold them that long (20 B per lane of scratch otherwise) and loads them where they are used
+      if constexpr (HELPERS > 0) load_warm();
       if constexpr (HELPERS > 0) {
 #pragma unroll
         for (int b = 0; b < 6; ++b)
@@ -1245,9 +1292,19 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       SS_PROF(8);
       // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
       // the rows y = Lambda w and w, the sweep's wrench and the G / T columns are held as three float pairs each
+      // warm start (PHYSICS.md 3.4): a corner that touched the SAME stone in the previous substep of this control step starts from
+      // that substep's impulses; every other corner from zero
+      if constexpr (HELPERS == 0) load_warm();
       float lam[4][3];
+      const int key = active | (det.cslot << 4);
+      int warm_any = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lam[k][0] = lam[k][1] = lam[k][2] = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const bool w = kPgsWarm && (((active & wkey_prev) >> k) & 1) && ((((wkey_prev ^ key) >> (4 + 2 * k)) & 3) == 0);
+        warm_any |= w ? 1 : 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) lam[k][d] = w ? wlam_prev[k][d] : 0.f;
+      }
       constexpr float mu = Model::friction;
       ssf2 Vp[3] = {{V[0], V[1]}, {V[2], V[3]}, {V[4], V[5]}};
       ssf2 Wp[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1291,6 +1348,28 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       // all LDS reads land before the loop: otherwise its body carries eleven `s_waitcnt lgkmcnt(n)` for the first iteration's sake
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), leave vmcnt / expcnt alone
 #endif
+      if constexpr (kPgsWarm) {
+        // the starting impulses move both feet before the first sweep: the own foot through y = Lambda_own w, the partner's foot
+        // through C (like a sweep's increments).  A lane pair without a warm corner skips it (the products would add zeros).
+        if ((warm_any | xchg_i(warm_any)) != 0) {
+          static_for<0, 12>([&](auto Rc) {
+            constexpr int row = decltype(Rc)::value, k = row / 3, d = row % 3;
+            const ssf2 l2 = {lam[k][d], lam[k][d]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Vp[i] = rYp[row][i] * l2 + Vp[i]; Wp[i] = rWp[row][i] * l2 + Wp[i]; }
+          });
+          ssf2 Wo[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Wo[i] = ssf2{xchg(Wp[i].x), xchg(Wp[i].y)};
+#pragma unroll
+          for (int l = 0; l < 6; ++l) {
+            const float sc = (l & 1) ? Wo[l >> 1].y : Wo[l >> 1].x;
+            const ssf2 s2 = {sc, sc};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Vp[i] = Cc[l][i] * s2 + Vp[i];
+          }
+        }
+      }
 #pragma unroll 1                       // (unrolled by 2 or fully: 0.0522 vs 0.0504 ms/step; C formed by the helpers after barrier #3
                                        // behind a sixth barrier instead of inside part B: no gain either)
       for (int it = 0; it < kCoupled; ++it) {
@@ -1313,6 +1392,21 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       sweep();
 #endif
       SV W = {{Wp[0].x, Wp[0].y, Wp[1].x}, {Wp[1].y, Wp[2].x, Wp[2].y}};
+      if constexpr (kPgsWarm) {        // what the next substep of this control step starts from
+        if constexpr (warm_in_lds(HELPERS)) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) L.s(S_WLAM + 3 * k + d) = lam[k][d];
+          L.s(S_WKEY) = __builtin_bit_cast(float, key);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wm.lam[k][d] = lam[k][d];
+          wm.key = key;
+        }
+      }
       SS_PROF(9);
       // accumulated foot wrenches -> whole tree: own leg up, pelvis biases summed over the pair, spine, base, down
 #ifndef SS_ABLATE_FINAL
@@ -1337,6 +1431,10 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L) {
       }
 #endif
   };
+  if (kPgsWarm && !in_contact) {                 // no contact in this substep: nothing to start the next one from
+    if constexpr (warm_in_lds(HELPERS)) L.s(S_WKEY) = 0.f;
+    else wm.key = 0;
+  }
   if constexpr (HELPERS == 0) {     // one block, the operators first (before the rows occupy the registers)
     if (in_contact) {
       JointCache jo;                   // opaque copies of the spine + leg records and the base factor

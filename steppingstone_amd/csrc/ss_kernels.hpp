@@ -697,8 +697,11 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   for (int i = 0; i < 16; ++i) prof.t[i] = 0;
   prof.last = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
+  Warm wm;                                     // contact impulses carried from substep to substep; every control step starts cold
+  warm_clear(wm);
+  if constexpr (kPgsWarm && warm_in_lds(HELPERS)) L.s(S_WKEY) = 0.f;
 #pragma unroll 1
-  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG power, fr, L);
+  for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) substep<Model, HELPERS>(SS_PROF_ARG power, fr, L, wm);
   SS_FUZZ(0x61u);
   SS_PROF(12);
   SS_MEMBAR();

@@ -8,15 +8,17 @@ Different construction from the oracle on purpose:
     (np_dynamics.forward_dynamics, which also supplies the free velocities) and explicit 6x27 foot Jacobians, and the
     Gauss-Seidel keeps no velocity at all: every row evaluates its relative velocity from the accumulated foot WRENCHES
     (`v = w . (V* + L_ff W_f + L_fg W_g(previous sweep))`), which is the same iteration written in impulse space.
-Both follow the same specification: 8 sweeps, Gauss-Seidel inside a foot (corners 0..3, normal then t1, t2), Jacobi
-between the two feet, lambda_n >= 0, friction pyramid |lambda_t| <= mu lambda_n, Baumgarte term, no warm start."""
+Both follow the same specification: 5 sweeps, Gauss-Seidel inside a foot (corners 0..3, normal then t1, t2), Jacobi
+between the two feet, lambda_n >= 0, friction pyramid |lambda_t| <= mu lambda_n, Baumgarte term; warm start: a corner that
+touched the same stone in the previous substep of the same control step starts from that substep's impulses (here: the
+accumulated wrenches start from sum w lambda_0; the oracle applies y lambda_0 to the foot twists)."""
 import numpy as np
 
 import np_dynamics as npd
 from steppingstone_amd import model as M
 
 H = npd.H_SUB
-STONE_R, REACH, ERP, SLOP, VCORR_MAX, SWEEPS = 0.25, 0.10, 0.2, 0.001, 2.0, 8
+STONE_R, REACH, ERP, SLOP, VCORR_MAX, SWEEPS = 0.25, 0.10, 0.2, 0.001, 2.0, 5
 FEET = (M.RIGHT_FOOT_BODY, M.LEFT_FOOT_BODY)
 
 
@@ -85,13 +87,19 @@ def rows(c):
     return np.array(W)
 
 
-def pgs(Li, Vfree, contacts, mu, sweeps=SWEEPS):
-    """Impulse-space statement of PHYSICS.md 3.4.  Returns lam [8,3] and the accumulated foot wrenches [2,6]."""
+def pgs(Li, Vfree, contacts, mu, sweeps=SWEEPS, lam0=None):
+    """Impulse-space statement of PHYSICS.md 3.4.  Returns lam [8,3] and the accumulated foot wrenches [2,6].  lam0 [8,3]: the
+    starting impulses (warm start; rows of corners without a contact are ignored)."""
     lam = np.zeros((8, 3))
     Wr = [rows(c) if c is not None else None for c in contacts]
     bn = [min(ERP * max(c["pen"] - SLOP, 0.0) / H, VCORR_MAX) if c is not None else 0.0 for c in contacts]
     L = [[Li[6 * a:6 * a + 6, 6 * b:6 * b + 6] for b in range(2)] for a in range(2)]
     wrench = np.zeros((2, 6))
+    if lam0 is not None:
+        for k, c in enumerate(contacts):
+            if c is not None:
+                lam[k] = lam0[k]
+                wrench[c["foot"]] = wrench[c["foot"]] + Wr[k].T @ lam[k]
     for _ in range(sweeps):
         seen = wrench.copy()                                   # what the OTHER foot is allowed to know during this sweep
         for k, c in enumerate(contacts):
@@ -113,9 +121,10 @@ def pgs(Li, Vfree, contacts, mu, sweeps=SWEEPS):
     return lam, wrench, Wr, bn
 
 
-def substep(m, st, tau_m, sweeps=SWEEPS):
+def substep(m, st, tau_m, sweeps=SWEEPS, warm=None):
     """One substep of PHYSICS.md 3 from a packed oracle state (oracle_lib layout).  Returns a dict with every
-    intermediate of the contact stage and the integrated state."""
+    intermediate of the contact stage and the integrated state.  warm: the `warm` entry of the previous substep's result when that
+    substep belongs to the same control step (None: cold start) -- (lam [8,3], stone index per corner or -1)."""
     pos, quat, v0, q, qd = st[0:3], st[3:7], st[7:13], st[13:34], st[34:55]
     n = int(st[59])
     terrain = st[65:185].reshape(20, 6)
@@ -129,10 +138,16 @@ def substep(m, st, tau_m, sweeps=SWEEPS):
     contacts = detect(m, pos, quat, q, terrain, n)
     out = dict(Li=Li, V0=Vfree, qdf=qdf, v0f=v0f, contacts=contacts)
     dv = np.zeros(6 + M.NJ)
+    out["warm"] = (np.zeros((8, 3)), [-1] * 8)
     if any(c is not None for c in contacts):
-        lam, wrench, Wr, bn = pgs(Li, Vfree, contacts, m["friction"], sweeps)
+        lam0 = None
+        if warm is not None:                  # a corner keeps its impulses only if it touched the SAME stone in the previous substep
+            lam0 = np.array([warm[0][k] if (c is not None and warm[1][k] == c["stone"]) else np.zeros(3) for k, c in enumerate(contacts)])
+        lam, wrench, Wr, bn = pgs(Li, Vfree, contacts, m["friction"], sweeps, lam0)
         dv = Hinv_Jt @ wrench.reshape(12)
         out.update(lam=lam, wrench=wrench, W=Wr, bn=bn)
+        out["warm"] = (np.array([lam[k] if c is not None else np.zeros(3) for k, c in enumerate(contacts)]),
+                       [c["stone"] if c is not None else -1 for c in contacts])
     out["dv0"], out["dqd"] = dv[:6], dv[6:]
     qd1, v1 = qdf + dv[6:], v0f + dv[:6]
     q1 = q + H * qd1

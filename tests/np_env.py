@@ -81,10 +81,11 @@ def control_step(m, st, act):
     tau = np.asarray(M.POLICY_SIGN, np.float64) * a * m["torque"]      # the action is in policy coordinates, PHYSICS.md 2
     n, count, elapsed = int(st[N]), int(st[COUNT]), int(st[ELAPSED])
     terrain = st[65:185].reshape(NUM_STONES, 6)
-    contacts, soles = None, None
+    contacts, soles, warm = None, None, None              # every control step starts its contact solve cold (PHYSICS.md 3.4)
     for _ in range(4):
         soles = sole_centres(m, st)                       # positions at the start of the substep, like the detector
-        out = npc.substep(m, st, tau)
+        out = npc.substep(m, st, tau, warm=warm)
+        warm = out["warm"]
         contacts = out["contacts"]
         st[:55] = out["state"]
     flags = 0

@@ -62,6 +62,7 @@ def load(prec="f32"):
     lib.sso_step_forced.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32]
     lib.sso_step_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, vp, vp, i32, vp, vp, i32]
     lib.sso_debug_contact.argtypes = [vp, i32, vp, vp]
+    lib.sso_debug_contact_after.argtypes = [vp, i32, vp, i32, vp]
     lib.sso_set_curriculum.argtypes = [vp, i32]
     lib.sso_set_specialist.argtypes = [vp, i32]
     lib.sso_set_sample_prob.argtypes = [vp, vp, i32]
@@ -183,13 +184,14 @@ class OracleEnv:
                              nul(nnear), nul(force), nul(nforce), int(cap), nul(trace), nul(replay), MAX_DECISIONS)
         return out
 
-    def debug_contact(self, e, tau):
+    def debug_contact(self, e, tau, prior=0):
         """ONE substep of env e under fixed motor torques (the env's state advances); returns the contact stage's
-        intermediate quantities as a dict of arrays (oracle/ss_oracle.c: contact_tap)."""
+        intermediate quantities as a dict of arrays (oracle/ss_oracle.c: contact_tap).  prior: that many substeps of the same
+        control step run first, so that the tapped one is warm-started from them (PHYSICS.md 3.4)."""
         tau = np.ascontiguousarray(tau, self.real)
         tap = np.zeros(1, tap_dtype(self.real))
         assert tap.nbytes == self.lib.sso_tap_size()
-        self.lib.sso_debug_contact(self.h, int(e), _p(tau), _p(tap))
+        self.lib.sso_debug_contact_after(self.h, int(e), _p(tau), int(prior), _p(tap))
         return {k: tap[k][0].copy() for k in tap.dtype.names}
 
     def set_curriculum(self, c):

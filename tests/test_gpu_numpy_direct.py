@@ -35,9 +35,10 @@ def numpy_control_step(m, st, act):
     tau = np.asarray(npc.M.POLICY_SIGN, np.float64) * np.clip(act, -1.0, 1.0) * m["torque"]      # action in policy coordinates
     s = st.astype(np.float64).copy()
     margin = np.inf
-    feet = [False, False]
+    feet, warm = [False, False], None
     for _ in range(4):
-        out = npc.substep(m, s, tau)
+        out = npc.substep(m, s, tau, warm=warm)
+        warm = out["warm"]
         margin = min(margin, detection_margin(m, s))
         feet = [any(c is not None and c["foot"] == f for c in out["contacts"]) for f in (0, 1)]
         s[:55] = out["state"]

@@ -633,33 +633,12 @@ def test_kernel_variants_are_bitwise_identical():
 def test_data_parallel_minibatch_step_is_captured_with_its_all_reduce():
     """the data-parallel minibatch step of ppo.train (gather, forward, backward, ONE RCCL all-reduce of the flat
     gradient, clip, capturable Adam) as a hipGraph.  No multi-GPU box here, so the collective is forced on a 1-rank RCCL group
-    (force_collective): the capture must succeed (no fallback) and replays must reproduce the eager data-parallel steps."""
-    import torch.distributed as dist
-    from steppingstone_amd import ppo
-    dev = torch.device("cuda:0")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29650 + os.getpid() % 300), rank=0, world_size=1, device_id=dev)
-        created = True
-    try:
-        torch.manual_seed(3)
-        data = (torch.randn(4096, 60, device=dev), torch.randn(4096, 21, device=dev).clamp(-1, 1), torch.randn(4096, 1, device=dev),
-                torch.randn(4096, 1, device=dev), -20 + torch.randn(4096, 1, device=dev), torch.randn(4096, 1, device=dev))
-        finals = []
-        for use_graph in (False, True):
-            torch.manual_seed(5)
-            ac = ppo.ActorCritic(num_ensembles=1).to(dev)
-            agent = ppo.PPO(ac, mini_batch_size=512, use_graph=use_graph, graph_collectives=True, force_collective=True)
-            g = torch.Generator(device=dev); g.manual_seed(11)
-            for k in range(8):
-                idx = torch.randperm(4096, device=dev, generator=g)[:512]
-                out = agent._graph_step(data, idx, refresh=(k == 0)) if use_graph else torch.stack(agent._gathered_step(data, idx))
-            if use_graph:
-                assert agent._graph_ok() and agent._graph is not None and agent.graph_fallback is None, agent.graph_fallback
-            finals.append((torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).clone(), out.clone()))
-        assert torch.allclose(finals[0][0], finals[1][0], atol=5e-4), float((finals[0][0] - finals[1][0]).abs().max())
-        assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-2, atol=1e-4)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    (force_collective): the capture must succeed (no fallback) and replays must reproduce the eager data-parallel steps.
+    Runs in a process of its own (tests/dp_graph_capture_check.py): a native abort inside RCCL / the graph capture (round 5 saw one
+    SIGABRT in autograd's backward under capture, not reproduced) then fails THIS test instead of taking the whole suite down."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "dp_graph_capture_check.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "dp graph capture ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])

@@ -181,9 +181,18 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     return score
 
 
+CURRICULA = [0]          # --curricula: terrains averaged in the score (0 = flat, 5 = the full yaw x pitch grid)
+PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of each coordinate's std): pulls numbers the score does not need back
+
+
 def _eval(args):
     x, S = args
-    return rollout(_W["kind"], overrides_of(_W["kind"], x, S))
+    ov = overrides_of(_W["kind"], x, S)
+    sc = float(np.mean([rollout(_W["kind"], ov, n=64 if len(CURRICULA) == 1 else 48, seed=9 + 100 * c, curriculum=c) for c in CURRICULA]))
+    if PRIOR:
+        std = np.array([s_[2] for s_ in S])
+        sc -= PRIOR * float(np.mean((np.asarray(x) / std) ** 2))
+    return sc
 
 
 # ------------------------------------------------------------------------------------------------ CMA-ES (Hansen, "The CMA evolution strategy: a tutorial")
@@ -241,9 +250,16 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="")
     ap.add_argument("--evaluate", default="", help="re-score a *_best.json on held-out seeds and on curriculum-5 terrain")
+    ap.add_argument("--ablate", default="", help="one-at-a-time reset of every coordinate of a *_best.json to the default")
     ap.add_argument("--resume", default="", help="start from the x of a *_best.json")
     ap.add_argument("--hours", type=float, default=0.0, help="stop after this much wall-clock time (0: by generations)")
+    ap.add_argument("--curricula", default="0", help="comma-separated curriculum levels averaged in the score")
+    ap.add_argument("--prior", type=float, default=0.0, help="L2 pull towards the specification's defaults (per mean squared std)")
+    ap.add_argument("--sigma0", type=float, default=0.0)
     args = ap.parse_args()
+    global CURRICULA, PRIOR
+    CURRICULA = [int(c) for c in args.curricula.split(",")]
+    PRIOR = args.prior
     S = space()
     names = [s[0] for s in S]
     std = np.array([s[2] for s in S])
@@ -256,6 +272,22 @@ def main():
                 sc, d = rollout(args.kind, ov, n=128, steps=800, seed=seed, curriculum=cur, detail=True)
                 print("%-24s curriculum %d seed %4d: %s" % (label, cur, seed, json.dumps(d)))
         return
+    if args.ablate:
+        # which of the identified numbers carry the result: every coordinate back to the specification's default, one at a time
+        best = json.load(open(args.ablate))
+        x = np.array([best["x"].get(n, 0.0) for n in names])
+        pool = mp.get_context("fork").Pool(args.workers, initializer=_init_worker, initargs=(args.kind,))
+        cand = [x * std]
+        for i in range(len(S)):
+            y = x.copy()
+            y[i] = 0.0
+            cand.append(y * std)
+        F = pool.map(_eval, [(c, S) for c in cand])
+        print("# %s: score of the identified model %.3f; score with ONE coordinate back at the specification's default (sorted by loss)" % (args.kind, F[0]))
+        for i in np.argsort(F[1:]):
+            print("%-24s x = %+6.2f std   score %.3f   (%+.3f)" % (names[i], x[i], F[1 + i], F[1 + i] - F[0]))
+        pool.close()
+        return
     out = args.out or os.path.join(ROOT, "gpurun_out", "sysid_%s" % args.kind)
     pool = mp.get_context("fork").Pool(args.workers, initializer=_init_worker, initargs=(args.kind,))
     # the search runs in units of each coordinate's own std: x_scaled = x / std, isotropic start
@@ -263,7 +295,7 @@ def main():
     if args.resume:
         b = json.load(open(args.resume))
         x0 = np.array([b["x"].get(n, 0.0) for n in names])
-    es = CMA(x0, 0.5 if args.resume else 1.0, args.popsize, seed=args.seed)
+    es = CMA(x0, args.sigma0 or (0.5 if args.resume else 1.0), args.popsize, seed=args.seed)
     base = pool.map(_eval, [(np.zeros(len(S)), S)])[0]
     print("# %s: %d parameters, population %d, %d workers; score = mean stones beyond the start + 0.004 x mean steps; the specification as it is: %.3f"
           % (args.kind, len(S), args.popsize, args.workers, base), flush=True)
