@@ -48,9 +48,12 @@ def space():
     S += [ADD("hip_z", 0.02, -0.10, 0.10), ADD("spine_r2", 0.02, -0.08, 0.08), ADD("spine_r0.z", 0.02, -0.10, 0.10),
           ADD("knee_gap", 0.01, -0.04, 0.05), ADD("ankle_gap", 0.01, -0.04, 0.05),
           ADD("sole.front", 0.02, -0.08, 0.10), ADD("sole.back", 0.02, -0.08, 0.06), ADD("sole.half_width", 0.01, -0.03, 0.05),
-          ADD("sole.z", 0.01, -0.04, 0.05)]
+          ADD("sole.z", 0.01, -0.04, 0.065)]
     for t in model.JOINT_TYPES:
         S.append(LOGM("torque." + t, 0.20, -1.6, 1.6))
+    # the spine on its own as well: the shipped Mike actor ignores the abdomen angles and emits nothing for the abdomen joints -- in the
+    # reference's Mike the spine is (nearly) rigid
+    S += [LOGM("abdomen.damping", 0.6, -3.0, 6.0), LOGM("abdomen.stiffness", 0.6, -3.0, 7.0)]
     S += [LOGM("scale.damping", 0.5, -5.0, 2.0), LOGM("scale.stiffness", 0.5, -5.0, 2.0), LOGM("scale.armature", 0.5, -4.0, 3.0),
           LOGM("k_lim_per_torque", 0.4, -2.5, 2.0), LOGM("d_lim_per_k", 0.4, -2.5, 2.0)]
     for t in model.JOINT_TYPES:
@@ -68,8 +71,11 @@ def overrides_of(kind, x, S):
     ov, rng = {}, {t: list(D["range"][t]) for t in model.JOINT_TYPES}
     sole = list(D["sole"])
     r0 = list(D["spine_r0"])
+    spine = {}
     for (name, how, _, lo, hi), v in zip(S, np.clip(x, [s[3] for s in S], [s[4] for s in S])):
-        if name.startswith("scale."):
+        if name.startswith("abdomen."):
+            spine[name.split(".")[1]] = float(np.exp(v))
+        elif name.startswith("scale."):
             key = name.split(".")[1]
             for t in model.JOINT_TYPES:
                 ov["%s.%s" % (key, t)] = D[key][t] * float(np.exp(v))
@@ -89,8 +95,14 @@ def overrides_of(kind, x, S):
             else:
                 d0 = D[name]
             ov[name] = d0 * float(np.exp(v)) if how == "log" else d0 + float(v)
+    for key, f in spine.items():                   # on top of the global scale
+        for t in ("abdomen_z", "abdomen_y", "abdomen_x"):
+            ov["%s.%s" % (key, t)] = ov.get("%s.%s" % (key, t), D[key][t]) * f
     for t in model.JOINT_TYPES:
         lo, hi = rng[t]
+        if t in ("abdomen_z", "abdomen_x"):        # the robot is mirror symmetric: the spine's z / x joints have symmetric ranges
+            half = 0.5 * (hi - lo)                 # (tools/gen_model_tables.py asserts it; the two-lane kernel relies on it)
+            lo, hi = -half, half
         if hi - lo < 10.0:                         # keep a joint a joint
             mid = 0.5 * (lo + hi)
             lo, hi = mid - 5.0, mid + 5.0
@@ -266,7 +278,7 @@ def main():
     if args.evaluate:
         _init_worker(args.kind)
         best = json.load(open(args.evaluate))
-        x = np.array([best["x"][n] for n in names])
+        x = np.array([best["x"].get(n, 0.0) for n in names])
         for label, ov in (("specification as it is", {}), ("identified model", overrides_of(args.kind, x * std, S))):
             for cur, seed in ((0, 9), (0, 1234), (0, 777), (5, 1234)):
                 sc, d = rollout(args.kind, ov, n=128, steps=800, seed=seed, curriculum=cur, detail=True)
