@@ -284,11 +284,28 @@ def _humanoid_at_density(P):
                 q0=q0, corners=corners, friction=float(P["friction"]))
 
 
-def build(kind, overrides=None):
-    """kind: 'walker3d' | 'mike' -> dict of float64 numpy arrays + scalars."""
+def identified(kind):
+    """The numbers identified against the reference's SHIPPED policy for this robot (tools/sysid_policy.py --emit ->
+    steppingstone_amd/identified_<kind>.json; DESIGN.md section 8, docs/PHYSICS.md section 2): overrides of DEFAULTS[kind] under which the
+    deterministic `playground/models/*_latest.pt` actor walks the stepping-stone course.  {} if no file is present."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "identified_%s.json" % kind)
+    if not os.path.exists(path):
+        return {}
+    ov = json.load(open(path))["overrides"]
+    return {k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}
+
+
+def build(kind, overrides=None, use_identified=True):
+    """kind: 'walker3d' | 'mike' -> dict of float64 numpy arrays + scalars.  The specification is DEFAULTS[kind] (rounds 1-4: own numbers
+    after the roboschool humanoid) with the identified overrides on top (round 5); `overrides` go on top of both;
+    use_identified=False evaluates the rounds-1-4 numbers (the prior the identification searches around)."""
     if kind not in DEFAULTS:
         raise ValueError("unknown robot kind %r" % (kind,))
-    m = _humanoid(params(kind, overrides))
+    ov = dict(identified(kind)) if use_identified else {}
+    ov.update(overrides or {})
+    m = _humanoid(params(kind, ov))
     m["kind"] = kind
     m["parent"] = np.array(PARENT, np.int32)
     m["axis"] = np.array(AXIS, np.int32)

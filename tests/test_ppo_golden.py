@@ -194,3 +194,50 @@ def test_legacy_reader_rejects_other_files(tmp_path):
         with pytest.raises(pickle.UnpicklingError, match="refused"):
             lc.read_legacy(str(evil))
         assert not (tmp_path / "pwned").exists()
+
+
+def test_export_in_the_form_the_reference_loads_back(tmp_path):
+    """tools/export_reference_checkpoint.py: a checkpoint of this package becomes a pickled `Policy` module of the REFERENCE's own classes
+    (playground/train.py:551 saves one, playground/enjoy.py:148 `torch.load`s one).  Here, where the reference checkout is present: the
+    exported file loads with plain torch.load, is an instance of common.controller.Policy, and its deterministic action, ensemble values
+    and log-std equal this package's; and it reads back through legacy_checkpoint-free means only -- the round trip ours -> theirs."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/common/controller.py"):
+        pytest.skip("reference checkout not present")
+    from steppingstone_amd import ppo
+    torch.manual_seed(4)
+    ac = ppo.ActorCritic(num_ensembles=2)
+    with torch.no_grad():
+        ac.logstd.copy_(torch.linspace(-2.0, -1.0, 21))
+    ours = str(tmp_path / "ours.pt")
+    ppo.save_checkpoint(ac, ours, update=7)
+    out = str(tmp_path / "theirs.pt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "export_reference_checkpoint.py"), ours, "--reference", "/root/reference",
+                        "--out", out], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    # load it the way playground/enjoy.py does, in a process that can import the reference's classes
+    code = ("import sys, types, torch\n"
+            "sys.dont_write_bytecode = True\n"
+            "sys.path.insert(0, '/root/reference')\n"
+            "g, sp = types.ModuleType('gym'), types.ModuleType('gym.spaces')\n"
+            "sp.Box, sp.Dict, sp.MultiDiscrete = type('Box', (), {}), type('Dict', (dict,), {}), type('MultiDiscrete', (), {})\n"
+            "g.spaces = sp; sys.modules.update({'gym': g, 'gym.spaces': sp})\n"
+            "m = torch.load(%r, weights_only=False)\n"
+            "from common.controller import Policy\n"
+            "assert isinstance(m, Policy) and len(m.critics) == 2\n"
+            "x = torch.linspace(-1, 1, 5 * 60).reshape(5, 60)\n"
+            "v, a, lp, _ = m.act(x, None, None, deterministic=True)\n"
+            "torch.save({'a': a, 'v': m.get_ensemble_values(x, None, None), 'logstd': m.dist.logstd._bias.reshape(-1)}, %r)\n"
+            % (out, str(tmp_path / "ref_out.pt")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = torch.load(str(tmp_path / "ref_out.pt"))
+    x = torch.linspace(-1, 1, 5 * 60).reshape(5, 60)
+    with torch.no_grad():
+        _, a, _ = ac.act(x, deterministic=True)
+        ve = ac.get_ensemble_values(x)
+    assert torch.allclose(ref["a"], a, atol=1e-6) and torch.allclose(ref["v"], ve, atol=1e-5)
+    assert torch.equal(ref["logstd"], ac.logstd.detach())

@@ -1,0 +1,30 @@
+"""The one reference-held behavioural signal about the env's PHYSICS: `playground/enjoy.py:143-235`
+loads `playground/models/*_latest.pt` and the policy walks the stepping-stone course.  Until round 4 the shipped deterministic actors
+fell after 1-2 stones in this env; with the robot numbers identified in round 5 (steppingstone_amd/identified_<kind>.json, DESIGN.md
+section 8) they walk it.  Runs WITHOUT the reference: the actors' weights are plain arrays under tests/golden/ (tools/make_golden_policy.py).
+CPU: the oracle behind the package's own VecEnv class.  INFORMATIONAL about PyBullet parity (never a claim), but a regression guard for
+the identified model: anything that breaks the robot the policies were trained on shows up here."""
+import numpy as np
+import pytest
+
+import shipped_actor as sa
+from oracle_backend import OracleBackend
+from steppingstone_amd.envs import SteppingStoneVecEnv, kind_of
+
+torch = pytest.importorskip("torch")
+
+# (env id, kind, envs, steps, mean stones beyond the start >=, median >=) on flat terrain
+CASES = [("Walker3DStepperEnv-v0", "walker3d", 32, 700, 8.0, 12.0),
+         ("MikeStepperEnv-v0", "mike", 32, 700, 4.0, 5.0)]
+
+
+@pytest.mark.parametrize("env_id,kind,n,steps,mean_min,median_min", CASES)
+def test_shipped_actor_walks_the_course_in_the_oracle(env_id, kind, n, steps, mean_min, median_min):
+    from steppingstone_amd import model
+    if not model.identified(kind):
+        pytest.skip("no identified numbers for %s yet (steppingstone_amd/identified_%s.json)" % (kind, kind))
+    env = SteppingStoneVecEnv(env_id, n, seed=31, return_numpy=False, backend=OracleBackend(kind_of(env_id), n, 31))
+    stones, length, alive = sa.walk(env, sa.load_actor(kind), steps, lambda o: o, n)
+    print("%s in the CPU oracle, flat terrain, %d envs: stones beyond the start mean %.2f median %.1f max %.0f, first-episode length mean %.0f" % (
+        kind, n, stones.mean(), np.median(stones), stones.max(), length.mean()))
+    assert stones.mean() >= mean_min and np.median(stones) >= median_min

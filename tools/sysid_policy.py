@@ -156,7 +156,7 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     from steppingstone_amd import model
     ol, lib, torch, actor = _W["ol"], _W["lib"], _W["torch"], _W["actor"]
     try:
-        m = model.build(kind, ov)
+        m = model.build(kind, ov, use_identified=False)        # the search is relative to the rounds-1-4 prior
     except Exception:
         return (-1.0, {}) if detail else -1.0
     sm = pack_model(m)
@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="")
     ap.add_argument("--evaluate", default="", help="re-score a *_best.json on held-out seeds and on curriculum-5 terrain")
+    ap.add_argument("--emit", default="", help="write steppingstone_amd/identified_<kind>.json from a *_best.json")
     ap.add_argument("--ablate", default="", help="one-at-a-time reset of every coordinate of a *_best.json to the default")
     ap.add_argument("--resume", default="", help="start from the x of a *_best.json")
     ap.add_argument("--hours", type=float, default=0.0, help="stop after this much wall-clock time (0: by generations)")
@@ -283,6 +284,30 @@ def main():
             for cur, seed in ((0, 9), (0, 1234), (0, 777), (5, 1234)):
                 sc, d = rollout(args.kind, ov, n=128, steps=800, seed=seed, curriculum=cur, detail=True)
                 print("%-24s curriculum %d seed %4d: %s" % (label, cur, seed, json.dumps(d)))
+        return
+    if args.emit:
+        # the identified overrides as a data file next to model.py (4 significant digits), re-scored after rounding
+        best = json.load(open(args.emit))
+        x = np.array([best["x"].get(n, 0.0) for n in names])
+        ov = overrides_of(args.kind, x * std, S)
+
+        def r4(v):
+            if isinstance(v, (tuple, list)):
+                return [r4(u) for u in v]
+            return float("%.4g" % v)
+        ov = {k: r4(v) for k, v in ov.items()}
+        _init_worker(args.kind)
+        rows = {}
+        for cur, seed in ((0, 9), (0, 1234), (2, 1234), (5, 1234)):
+            _, d = rollout(args.kind, {k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}, n=128, steps=800, seed=seed,
+                           curriculum=cur, detail=True)
+            rows["curriculum %d seed %d" % (cur, seed)] = d
+            print("curriculum %d seed %4d: %s" % (cur, seed, json.dumps(d)))
+        path = os.path.join(ROOT, "steppingstone_amd", "identified_%s.json" % args.kind)
+        json.dump({"kind": args.kind, "what": "overrides of steppingstone_amd.model.DEFAULTS[kind] identified against the reference's shipped "
+                   "policy " + POLICY[args.kind] + " (tools/sysid_policy.py; DESIGN.md section 8)", "search_score": best.get("score"),
+                   "search_generation": best.get("generation"), "shipped_policy_in_this_model": rows, "overrides": ov}, open(path, "w"), indent=1)
+        print("wrote", path)
         return
     if args.ablate:
         # which of the identified numbers carry the result: every coordinate back to the specification's default, one at a time
