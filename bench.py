@@ -620,6 +620,11 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
     for key, learner, mb in (("torch", "torch", MB), ("torch_scaled", "torch", MB_SCALED), ("fused", "fused", MB)):
         if learner == "fused" and world > 1 and os.environ.get("SS_BENCH_TEST_TRANSPORT"):
             continue
+        if learner == "fused":        # outside SURVEY section 8, opt-in: the side row exists only where its library has been built
+            from steppingstone_amd import fused_ppo
+            if not os.path.exists(fused_ppo.LIB_PATH):
+                rows[key] = {"value": None, "note": "opt-in fused learner not built (SS_BUILD_LEARNER=1 python -m steppingstone_amd.build)"}
+                continue
         PHASE["name"] = "ppo row %s (minibatch %d)" % (key, mb)
         envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n_local, seed=8, device=dev, env_id_offset=rank * n_local, return_numpy=False)
         stamps = []

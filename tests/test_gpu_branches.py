@@ -133,7 +133,7 @@ def test_per_env_grids_at_full_size():
         o.set_state(st); g.set_state(st)
         drawn = np.zeros(n, bool)
         flips = 0
-        for t in range(3):
+        for t in range(5):
             oo, ro, do, io, mg = o.step_margins(zero)
             g.step(zero)
             sg, so = g.get_state().cpu().numpy(), o.get_state()
@@ -145,7 +145,7 @@ def test_per_env_grids_at_full_size():
             assert np.abs(sg[same, 65:185] - so[same, 65:185]).max() < 1e-5, path
             drawn |= io["update_terrain"].astype(bool)
             g.set_state(so)
-        assert flips <= 8, flips
+        assert flips <= 12, flips      # (5 steps x 4096 envs; round 4: 3 steps, <= 8)
         assert drawn.mean() > 0.5
         # the draws really differ between envs (a shared grid would put everybody in few cells)
         phi3 = o.get_state()[drawn, 65 + 3 * 6 + 3]

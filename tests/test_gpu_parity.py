@@ -164,7 +164,7 @@ def test_target_advance_and_sampler_are_bit_exact(env_id, kind):
     g.set_state(_stand_on_target(o, n))
     zero = np.zeros((n, 21), np.float32)
     advanced = np.zeros(n, bool)
-    for t in range(3):
+    for t in range(5):          # (released 1 cm above the stone: the feet are down for two consecutive steps by step 3-5)
         oo, ro, do, io = o.step(zero)
         og, rg, dg, ig = g.step(zero)
         raw = g._info.cpu().numpy()

@@ -48,7 +48,7 @@ def test_target_advance_and_sampler_match_oracle():
     o.set_state(st)
     zero = np.zeros((n, 21), np.float32)
     adv = np.zeros(n, bool)
-    for t in range(3):
+    for t in range(5):          # (the robot is released 1 cm above the stone: the feet are down for two consecutive steps by step 3-5)
         st = o.get_state()
         oo, ro, do, io = o.step(zero)
         so = o.get_state()

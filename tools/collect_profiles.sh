@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-( cd $R && timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > $O/${tag}_pytest_gpu.log
+( cd $R && timeout 2400 python -m pytest tests -m gpu -x -q -rs --durations=12 2>&1; echo "pytest rc $?" ) > $O/${tag}_pytest_gpu.log
 ( cd $R && python bench.py ) > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline > $O/${tag}_bench_under_rocprof.json 2>/dev/null
 cp $(ls /tmp/kt/*/*kernel_stats.csv | head -1) $O/${tag}_rocprofv3_kernel_stats.csv
