@@ -46,7 +46,8 @@ typedef SSO_REAL real;
 #define H_SUB ((real)(1.0 / 240.0))
 #define DT_CTRL ((real)(1.0 / 60.0))
 #define GRAV ((real)9.8)
-#define STONE_R ((real)0.25)
+#define STONE_R ((real)SSO_STONE_CONTACT_RADIUS)   /* contact radius of a stone (ss_model_tables.h; PHYSICS.md 3.3) */
+#define STEP_RADIUS ((real)0.25)                    /* the reference's step_radius: scale of the step bonus (PHYSICS.md 4.5) */
 #define PGS_ITERS 5   /* PHYSICS.md 3.4 (Bullet's numSolverIterations = 5); rounds 1-4: 8 */
 #define PGS_WARM 1    /* warm start from the previous substep of the same control step; rounds 1-4: none */
 #define ERP ((real)0.2)
@@ -399,6 +400,9 @@ static void stone_normal(const real* st, real nrm[3]) {
   nrm[0] = Rs.m[0][2]; nrm[1] = Rs.m[1][2]; nrm[2] = Rs.m[2][2];
 }
 
+/* contact radius of a stone (tools/sysid_policy.py's terrain study ONLY; the specification's value is STONE_R) */
+static real g_stone_r = STONE_R;
+void sso_debug_set_stone_radius(double r) { g_stone_r = (real)r; }
 static void detect(const sso_model* M, const env_state* s, const work* w, contact ct[8], foot_report* fr) {
   int n = s->n;
   int idx[3] = {n - 1 < 0 ? 0 : n - 1, n, n + 1 > NSTONE - 1 ? NSTONE - 1 : n + 1};
@@ -422,10 +426,10 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real d = dv[0] * nrm[0] + dv[1] * nrm[1] + dv[2] * nrm[2];
         real lx = dv[0] - d * nrm[0], ly = dv[1] - d * nrm[1], lz = dv[2] - d * nrm[2];
         real rho2 = lx * lx + ly * ly + lz * lz;
-        real g1 = -d, g2 = d + (real)0.10, g3 = g_dec ? STONE_R - r_sqrt(rho2) : 0;
+        real g1 = -d, g2 = d + (real)0.10, g3 = g_dec ? g_stone_r - r_sqrt(rho2) : 0;
         real gm = g1 < g2 ? g1 : g2;
         if (g3 < gm) gm = g3;
-        int touch = decide(0, d < 0 && d > (real)-0.10 && rho2 < STONE_R * STONE_R, gm);
+        int touch = decide(0, d < 0 && d > (real)-0.10 && rho2 < g_stone_r * g_stone_r, gm);
         /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
          * forced against d >= 0) */
         int wins = decide(0, !c->active || d < best, (touch && c->active) ? d - best : FAR_MARGIN);
@@ -763,7 +767,7 @@ static void env_step(const sso_env* E, int e, const float* act, float* obs, floa
     s->count += 1;
     if (s->count == 1) {
       real d0 = planar_dist(fr.sole[0], s->terrain[n_old]), d1 = planar_dist(fr.sole[1], s->terrain[n_old]);
-      step_bonus = 50 * r_exp(-(d0 < d1 ? d0 : d1) / (real)0.25);
+      step_bonus = 50 * r_exp(-(d0 < d1 ? d0 : d1) / STEP_RADIUS);
     }
     if (s->count >= 2 && s->n < NSTONE - 1) {
       s->n += 1; s->count = 0; advanced = 1;

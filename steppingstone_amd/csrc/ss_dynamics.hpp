@@ -29,7 +29,7 @@ namespace ss {
 constexpr float kH = 1.0f / 240.0f;
 constexpr float kDt = 1.0f / 60.0f;
 constexpr float kGrav = 9.8f;
-constexpr float kStoneR2 = 0.25f * 0.25f;
+constexpr float kStoneR2 = kStoneContactRadius * kStoneContactRadius;   // ss_model_tables.hpp (PHYSICS.md 3.3)
 // PHYSICS.md 3.4: 5 sweeps, warm-started from the previous substep of the same control step (Bullet's
 // numSolverIterations = 5 with warm starting; rounds 1-4 ran 8 cold sweeps -- DESIGN.md section 5.1 has the measured trade)
 #ifndef SS_PGS_ITERS

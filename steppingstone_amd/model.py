@@ -297,6 +297,21 @@ def identified(kind):
     return {k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}
 
 
+def env_constants(use_identified=True):
+    """Constants of the ENV (not of a robot) that the identification touched.  stone_contact_radius: the radius around a stone's centre
+    within which a sole corner can touch it (docs/PHYSICS.md 3.3).  Rounds 1-4: 0.25 m = the reference's `step_radius`, which its
+    target / bonus logic uses; round 5 (steppingstone_amd/identified_env.json): the shipped policies of BOTH robots get
+    markedly further on non-flat terrain when the physical stepping surface is larger than that disc, as the reference's plank-shaped
+    step bodies would be.  The 0.25 m of the step bonus and the target logic (PHYSICS.md 4.5) is unchanged."""
+    import json
+    import os
+    c = {"stone_contact_radius": 0.25}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "identified_env.json")
+    if use_identified and os.path.exists(path):
+        c.update(json.load(open(path))["constants"])
+    return c
+
+
 def build(kind, overrides=None, use_identified=True):
     """kind: 'walker3d' | 'mike' -> dict of float64 numpy arrays + scalars.  The specification is DEFAULTS[kind] (rounds 1-4: own numbers
     after the roboschool humanoid) with the identified overrides on top (round 5); `overrides` go on top of both;

@@ -18,7 +18,7 @@ import np_dynamics as npd
 from steppingstone_amd import model as M
 
 H = npd.H_SUB
-STONE_R, REACH, ERP, SLOP, VCORR_MAX, SWEEPS = 0.25, 0.10, 0.2, 0.001, 2.0, 5
+STONE_R, REACH, ERP, SLOP, VCORR_MAX, SWEEPS = float(np.float32(M.env_constants()["stone_contact_radius"])), 0.10, 0.2, 0.001, 2.0, 5
 FEET = (M.RIGHT_FOOT_BODY, M.LEFT_FOOT_BODY)
 
 

@@ -8,7 +8,7 @@ import pytest
 import oracle_lib as ol
 import parity_rule as pr
 from steppingstone_amd import model
-from controllers import balance_controller
+from controllers import balance_controller, standing_state
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -379,7 +379,12 @@ def test_closed_loop_1000_step_drift(env_id, kind):
     g = gpu_env(env_id, n, seed=3)
     o32, o64 = ol.OracleEnv(kind, n, seed=3), ol.OracleEnv(kind, n, seed=3, prec="f64")
     ctrl = balance_controller(kind)
-    obs = {"hip": g.reset(), "f32": o32.reset(), "f64": o64.reset()}
+    g.reset(); o32.reset(); o64.reset()
+    # all three start standing (tests/controllers.py: the balanced pose; the round-5 robot's reset pose is a walker's starting crouch)
+    st0 = standing_state(kind, o32.get_state())
+    g.set_state(st0); o32.set_state(st0); o64.set_state(st0.astype(np.float64))
+    og0 = g.get_obs()
+    obs = {"hip": og0.cpu().numpy() if hasattr(og0, "cpu") else np.array(og0), "f32": o32.get_obs(), "f64": o64.get_obs()}
     alive = np.ones(n, bool)
     rng = np.random.default_rng(0)
     curve = []
@@ -422,10 +427,13 @@ def test_episode_return_is_the_fp64_sum_of_the_step_rewards():
     n = 256
     g = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=3, device="cuda:0", return_numpy=False)
     g.reset()
+    st0 = g.get_state().cpu().numpy()
+    st0[:n // 2] = standing_state("walker3d", st0[:n // 2])      # half the robots start standing and are kept standing ...
+    g.set_state(st0)
     acc = np.zeros(n, np.float64)
     checked, longest, worst32 = 0, 0, 0.0
-    ctrl = balance_controller("walker3d")       # half the robots stand for the full 1000-step episode, the others act randomly
-    obs = g._obs
+    ctrl = balance_controller("walker3d")       # ... for the full 1000-step episode by the controller; the others act randomly
+    obs = g.get_obs()
     for t in range(1100):
         act = g.random_actions(t)
         act[:n // 2] = torch.as_tensor(ctrl(obs[:n // 2].cpu().numpy()), device="cuda:0")

@@ -18,13 +18,15 @@ def contact_states(kind, rng):
     oracle (falls, partial contacts, both feet / one foot), (b) robots standing on a stone that is tilted and turned
     under them (x / y tilt up to 15 deg, phi up to 20 deg: the stones a walking robot meets at curriculum 5)."""
     out = []
-    o = ol.OracleEnv(kind, 24, seed=int(rng.integers(1 << 30)), prec="f64")
+    o = ol.OracleEnv(kind, 48, seed=int(rng.integers(1 << 30)), prec="f64")
     o.set_curriculum(5)
     o.reset()
     for t in range(36):
         o.step(o.random_actions(t))
         if t % 3 == 2:
             out += list(o.get_state()[::2])
+        if t < 12 and t % 2 == 1:                  # the first steps after a reset: both feet on the stone
+            out += list(o.get_state()[1::4])
     deg = np.pi / 180
     m = npc.rounded_model(kind)
     for tilt in (4.0, 9.0, 15.0):                 # small tilts keep both feet down, large ones leave one foot in the air

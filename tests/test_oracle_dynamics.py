@@ -148,9 +148,13 @@ def test_resting_contact_is_bounded(kind):
         flags = env.substeps(0, np.zeros(21), 4)
         st = env.get_state()[0].astype(np.float64)
         pos, rot = ol.debug_fk(kind, st)
+        rc = M.env_constants()["stone_contact_radius"]
         for b in (M.RIGHT_FOOT_BODY, M.LEFT_FOOT_BODY):
-            zc = [(pos[b] + rot[b] @ c)[2] for c in m["corners"]]
-            assert min(zc) > -0.012, (k, b, min(zc))
+            P = [pos[b] + rot[b] @ c for c in m["corners"]]
+            # corners over stone 0 (within its contact radius of the axis at the origin) are held by the contact model; a corner that
+            # hangs over the rim is not (the round-5 robot's reset crouch puts its heels near the rim of a 0.25 m stone)
+            zc = [p[2] for p in P if np.hypot(p[0], p[1]) < rc - 0.005]
+            assert len(zc) >= 2 and min(zc) > -0.012, (k, b, zc)
         assert np.isfinite(st).all()
         assert np.abs(st[ol.S_VEL]).max() < 10 and np.abs(st[ol.S_QD]).max() < 60
     assert flags[0] == 1 and flags[1] == 1

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol  # noqa: E402
-from controllers import balance_controller  # noqa: E402
+from controllers import balance_controller, standing_state  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "walker3d"
 noise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
@@ -28,7 +28,14 @@ try:
 except ImportError:
     pass
 ctrl = balance_controller(kind)
-obs = {k: e.reset() for k, e in envs.items()}
+for e in envs.values():
+    e.reset()
+st0 = standing_state(kind, envs["f32"].get_state())       # the closed-loop tests start standing (tests/controllers.py)
+obs = {}
+for k, e in envs.items():
+    e.set_state(st0.astype(np.float64) if k == "f64" else st0)
+    o_ = e.get_obs()
+    obs[k] = o_.cpu().numpy() if hasattr(o_, "cpu") else np.array(o_)
 alive = np.ones(n, bool)
 rng = np.random.default_rng(0)
 print("%s, %d envs, action noise %.3f, implementations: %s" % (kind, n, noise, ", ".join(envs)))

@@ -133,10 +133,11 @@ def main():
                 print("%-8s curriculum %d %-6s n=%d seed=%d %s: %s" % (kind, cur, src, n, seed, c["launch"], txt))
                 print("   HELD TO THE FLAT 1e-4: %.1f %% | escape hatches: sensitive %d, other branch %d, other branch + sensitive %d, integer mismatch "
                       "excused %d, loose %d, beyond %d, FAILURES %d | err / bound 99.9 %% %.3f max %.3f | within 1e-4 of the oracle as it ran: %.2f %% | "
-                      "farther than 1e-4 from fp64: kernel %d, fp32 CPU oracle %d | burn-in episodes ended: %d (mean stones reached %.2f) | %.0f s" % (
+                      "farther than 1e-4 from fp64: kernel %d, fp32 CPU oracle %d | bound median %.2e 90 %% %.2e | burn-in episodes ended: %d (mean stones "
+                      "reached %.2f) | %.0f s" % (
                           100 * c["held_to_flat_1e4"], c["sensitive"], c["other_branch"], c["other_branch_sensitive"], c["int_excused"], c["loose"],
                           c["beyond"], c["failures"], c["q999_err_over_bound"], c["max_err_over_bound"], 100 * c["within_1e4_of_oracle"],
-                          c["far_from_fp64_hip"], c["far_from_fp64_cpu_fp32"], walked[1], walked[0], c["seconds"]), flush=True)
+                          c["far_from_fp64_hip"], c["far_from_fp64_cpu_fp32"], c["bound_median"], c["bound_q90"], walked[1], walked[0], c["seconds"]), flush=True)
                 for i in np.nonzero(~R["ok"] | R["beyond"])[0][:8]:
                     print("   %s env-step %d: category %d near %s | obs err %.2e / bound %.2e | reward %.2e / %.2e | pose %.2e / %.2e | velocities "
                           "%.2e / %.2e | integers equal %s" % ("FAILED" if not R["ok"][i] else "beyond its bound (counted)", i, R["category"][i],
@@ -148,10 +149,11 @@ def main():
     c = pa.counts(T)
     print("\nTOTAL %d held-out env-steps, %d cells: HELD TO THE FLAT 1e-4: %.1f %% | sensitive %d (%.1f %%), other branch %d, other branch + sensitive %d, "
           "integer mismatch excused %d, loose %d (%.3f %%), beyond %d, FAILURES %d | err / bound 99.9 %% %.3f max %.3f | within 1e-4 of the oracle as it "
-          "ran: %.2f %% | farther than 1e-4 from fp64: kernel %d, fp32 CPU oracle %d" % (
+          "ran: %.2f %% | farther than 1e-4 from fp64: kernel %d, fp32 CPU oracle %d | bound median %.2e, 90 %% %.2e" % (
               c["env_steps"], len(rows), 100 * c["held_to_flat_1e4"], c["sensitive"], 100.0 * c["sensitive"] / c["env_steps"], c["other_branch"],
               c["other_branch_sensitive"], c["int_excused"], c["loose"], 100.0 * c["loose"] / c["env_steps"], c["beyond"], c["failures"],
-              c["q999_err_over_bound"], c["max_err_over_bound"], 100 * c["within_1e4_of_oracle"], c["far_from_fp64_hip"], c["far_from_fp64_cpu_fp32"]))
+              c["q999_err_over_bound"], c["max_err_over_bound"], 100 * c["within_1e4_of_oracle"], c["far_from_fp64_hip"], c["far_from_fp64_cpu_fp32"],
+              c["bound_median"], c["bound_q90"]))
     if args.json:
         json.dump(dict(total=c, cells=rows, rule_sha256=have), open(args.json, "w"), indent=1)
     try:

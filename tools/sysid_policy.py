@@ -34,7 +34,7 @@ POLICY = {"walker3d": "mocca_envs:Walker3DStepperEnv-v0_latest.pt", "mike": "moc
 
 # ------------------------------------------------------------------------------------------------ the search space
 # (name, kind of coordinate, initial std in search units, lo, hi).  "log": multiplier exp(x) on the default; "add": default + x.
-LOGM = lambda name, std=0.20, lo=-1.4, hi=1.4: (name, "log", std, lo, hi)      # noqa: E731
+LOGM = lambda name, std=0.20, lo=-2.0, hi=2.0: (name, "log", std, lo, hi)      # noqa: E731
 ADD = lambda name, std, lo, hi: (name, "add", std, lo, hi)                      # noqa: E731
 
 
@@ -44,9 +44,9 @@ def space():
     for g in model.MASS_GROUPS:
         S.append(LOGM("mass_mult." + g))
     for k in ("thigh", "shin", "upper_arm", "lower_arm", "hip_y", "torso_w"):
-        S.append(LOGM(k, 0.08, -0.5, 0.5))
-    S += [ADD("hip_z", 0.02, -0.10, 0.10), ADD("spine_r2", 0.02, -0.08, 0.08), ADD("spine_r0.z", 0.02, -0.10, 0.10),
-          ADD("knee_gap", 0.01, -0.04, 0.05), ADD("ankle_gap", 0.01, -0.04, 0.05),
+        S.append(LOGM(k, 0.08, -0.8, 0.8))
+    S += [ADD("hip_z", 0.02, -0.15, 0.15), ADD("spine_r2", 0.02, -0.08, 0.08), ADD("spine_r0.z", 0.02, -0.10, 0.10),
+          ADD("knee_gap", 0.01, -0.043, 0.06), ADD("ankle_gap", 0.01, -0.04, 0.05),
           ADD("sole.front", 0.02, -0.08, 0.10), ADD("sole.back", 0.02, -0.08, 0.06), ADD("sole.half_width", 0.01, -0.03, 0.05),
           ADD("sole.z", 0.01, -0.04, 0.065)]
     for t in model.JOINT_TYPES:
@@ -54,13 +54,16 @@ def space():
     # the spine on its own as well: the shipped Mike actor ignores the abdomen angles and emits nothing for the abdomen joints -- in the
     # reference's Mike the spine is (nearly) rigid
     S += [LOGM("abdomen.damping", 0.6, -3.0, 6.0), LOGM("abdomen.stiffness", 0.6, -3.0, 7.0)]
-    S += [LOGM("scale.damping", 0.5, -5.0, 2.0), LOGM("scale.stiffness", 0.5, -5.0, 2.0), LOGM("scale.armature", 0.5, -4.0, 3.0),
+    S += [LOGM("scale.damping", 0.5, -5.0, 2.0), LOGM("scale.stiffness", 0.5, -5.0, 4.0), LOGM("scale.armature", 0.5, -4.0, 3.0),
           LOGM("k_lim_per_torque", 0.4, -2.5, 2.0), LOGM("d_lim_per_k", 0.4, -2.5, 2.0)]
     for t in model.JOINT_TYPES:
-        S += [ADD("range_lo." + t, 6.0, -40.0, 40.0), ADD("range_hi." + t, 6.0, -40.0, 40.0)]
-    S += [ADD("q0_deg.hip_y", 4.0, -25.0, 25.0), ADD("q0_deg.knee", 6.0, -22.0, 40.0), ADD("q0_deg.ankle", 4.0, -25.0, 25.0),
-          ADD("q0_deg.elbow", 8.0, -60.0, 18.0)]
-    S.append(LOGM("friction", 0.15, -0.9, 0.8))
+        S += [ADD("range_lo." + t, 6.0, -60.0, 60.0), ADD("range_hi." + t, 6.0, -60.0, 60.0)]
+    S += [ADD("q0_deg.hip_y", 4.0, -45.0, 25.0), ADD("q0_deg.knee", 6.0, -22.0, 75.0), ADD("q0_deg.ankle", 4.0, -25.0, 25.0),
+          ADD("q0_deg.elbow", 8.0, -60.0, 60.0)]
+    S.append(LOGM("friction", 0.15, -0.9, 1.2))
+    # the one ENV constant in the search: the radius within which a sole corner touches a stone (PHYSICS.md 3.3; rounds 1-4: 0.25 m, the
+    # reference's step_radius -- but its physical stepping surfaces may be larger than the disc its reward logic uses)
+    S.append(ADD("env.stone_radius", 0.03, -0.05, 0.30))
     return S
 
 
@@ -73,7 +76,9 @@ def overrides_of(kind, x, S):
     r0 = list(D["spine_r0"])
     spine = {}
     for (name, how, _, lo, hi), v in zip(S, np.clip(x, [s[3] for s in S], [s[4] for s in S])):
-        if name.startswith("abdomen."):
+        if name == "env.stone_radius":
+            ov["env.stone_radius"] = 0.25 + float(v)
+        elif name.startswith("abdomen."):
             spine[name.split(".")[1]] = float(np.exp(v))
         elif name.startswith("scale."):
             key = name.split(".")[1]
@@ -155,6 +160,10 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     """deterministic shipped actor in the oracle with model overrides `ov`: first episode of each of n envs"""
     from steppingstone_amd import model
     ol, lib, torch, actor = _W["ol"], _W["lib"], _W["torch"], _W["actor"]
+    ov = dict(ov)
+    stone_r = ov.pop("env.stone_radius", None)
+    lib.sso_debug_set_stone_radius.argtypes = [C.c_double]
+    lib.sso_debug_set_stone_radius(float(stone_r) if stone_r is not None else SPEC_STONE_RADIUS)
     try:
         m = model.build(kind, ov, use_identified=False)        # the search is relative to the rounds-1-4 prior
     except Exception:
@@ -193,6 +202,7 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     return score
 
 
+SPEC_STONE_RADIUS = 0.25 # what a model without an "env.stone_radius" override is evaluated with
 CURRICULA = [0]          # --curricula: terrains averaged in the score (0 = flat, 5 = the full yaw x pitch grid)
 PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of each coordinate's std): pulls numbers the score does not need back
 
@@ -262,6 +272,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="")
     ap.add_argument("--evaluate", default="", help="re-score a *_best.json on held-out seeds and on curriculum-5 terrain")
+    ap.add_argument("--stone-radius", type=float, default=0.0, help="--emit / --evaluate: the stone contact radius to evaluate with")
     ap.add_argument("--emit", default="", help="write steppingstone_amd/identified_<kind>.json from a *_best.json")
     ap.add_argument("--ablate", default="", help="one-at-a-time reset of every coordinate of a *_best.json to the default")
     ap.add_argument("--resume", default="", help="start from the x of a *_best.json")
@@ -296,17 +307,20 @@ def main():
                 return [r4(u) for u in v]
             return float("%.4g" % v)
         ov = {k: r4(v) for k, v in ov.items()}
+        env_consts = {k: ov.pop(k) for k in list(ov) if k.startswith("env.")}
+        if args.stone_radius:
+            env_consts["env.stone_radius"] = args.stone_radius        # the value adopted for BOTH robots (an env constant)
         _init_worker(args.kind)
         rows = {}
         for cur, seed in ((0, 9), (0, 1234), (2, 1234), (5, 1234)):
-            _, d = rollout(args.kind, {k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}, n=128, steps=800, seed=seed,
-                           curriculum=cur, detail=True)
+            _, d = rollout(args.kind, dict({k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}, **env_consts), n=128, steps=800,
+                           seed=seed, curriculum=cur, detail=True)
             rows["curriculum %d seed %d" % (cur, seed)] = d
             print("curriculum %d seed %4d: %s" % (cur, seed, json.dumps(d)))
         path = os.path.join(ROOT, "steppingstone_amd", "identified_%s.json" % args.kind)
         json.dump({"kind": args.kind, "what": "overrides of steppingstone_amd.model.DEFAULTS[kind] identified against the reference's shipped "
                    "policy " + POLICY[args.kind] + " (tools/sysid_policy.py; DESIGN.md section 8)", "search_score": best.get("score"),
-                   "search_generation": best.get("generation"), "shipped_policy_in_this_model": rows, "overrides": ov}, open(path, "w"), indent=1)
+                   "search_generation": best.get("generation"), "evaluated_with_env_constants": env_consts, "shipped_policy_in_this_model": rows, "overrides": ov}, open(path, "w"), indent=1)
         print("wrote", path)
         return
     if args.ablate:
@@ -332,6 +346,7 @@ def main():
     if args.resume:
         b = json.load(open(args.resume))
         x0 = np.array([b["x"].get(n, 0.0) for n in names])
+        x0 = np.clip(x0 * std, [s_[3] for s_ in S], [s_[4] for s_ in S]) / std        # a coordinate that ran past its bound restarts ON it
     es = CMA(x0, args.sigma0 or (0.5 if args.resume else 1.0), args.popsize, seed=args.seed)
     base = pool.map(_eval, [(np.zeros(len(S)), S)])[0]
     print("# %s: %d parameters, population %d, %d workers; score = mean stones beyond the start + 0.004 x mean steps; the specification as it is: %.3f"

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Cross-entropy search for the gains of tests/controllers.py (the committed stabilising controller of the closed-loop tests) against
+the fp32 CPU oracle: joint-space PD to the nominal pose + torso pitch / roll feedback must keep the robot standing on stone 0 for the
+full 1000-step episode under the tests' action noise (0.05).  Re-run whenever the robot's numbers change (round 5: the model identified
+against the shipped policies).  Nothing here comes from the reference or its policies.
+
+  python tools/tune_balance_controller.py walker3d [--iters 14]      -> prints a GAINS row for tests/controllers.py"""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def _init():
+    os.environ["OMP_NUM_THREADS"] = "1"
+
+
+def survival(args):
+    kind, gains, seed, steps = args
+    import controllers
+    import oracle_lib as ol
+    controllers.GAINS[kind] = tuple(gains)
+    ctrl = controllers.balance_controller(kind)
+    n = 24
+    o = ol.OracleEnv(kind, n, seed=seed)
+    o.set_auto_reset(False)
+    o.reset()
+    o.set_state(controllers.standing_state(kind, o.get_state()))      # the closed-loop tests start from the balanced pose
+    obs = o.get_obs()
+    rng = np.random.default_rng(seed)
+    alive = np.ones(n, bool)
+    life = np.zeros(n)
+    for t in range(steps):
+        a = np.clip(ctrl(obs) + 0.05 * rng.standard_normal((n, 21)).astype(np.float32), -1, 1).astype(np.float32)
+        obs, r, d, info = o.step(a)
+        life[alive] += 1
+        alive &= ~d.astype(bool)
+        if not alive.any():
+            break
+    o.close()
+    return float(life.mean())
+
+
+def main():
+    kind = sys.argv[1]
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 14
+    import controllers
+    mean = np.array(controllers.GAINS[kind], float)
+    std = np.maximum(0.6 * np.abs(mean), 0.05)
+    pool = mp.Pool(int(os.environ.get("WORKERS", "4")), initializer=_init)
+    rng = np.random.default_rng(0)
+    best, best_f = mean.copy(), pool.map(survival, [(kind, mean, 1, 1000)])[0]
+    print("start: %.1f steps" % best_f, flush=True)
+    for it in range(iters):
+        steps = 500 if best_f < 450 else 1000
+        X = mean + std * rng.standard_normal((48, len(mean)))
+        X[:, :10] = np.abs(X[:, :10])          # the position gains (10, 11) may take either sign
+        F = pool.map(survival, [(kind, x, 1 + it % 3, steps) for x in X])
+        order = np.argsort(F)[::-1]
+        elite = X[order[:8]]
+        mean, std = elite.mean(axis=0), np.maximum(elite.std(axis=0), 0.05 * np.abs(mean) + 2e-3)
+        if F[order[0]] >= best_f or steps == 1000:
+            cand = X[order[0]]
+            f1000 = np.mean(pool.map(survival, [(kind, cand, s, 1000) for s in (1, 2, 3)]))
+            if f1000 > best_f:
+                best, best_f = cand.copy(), f1000
+        print("iter %2d: best of generation %.1f (horizon %d), mean of elite %.1f; best so far %.1f of 1000" % (
+            it, F[order[0]], steps, np.mean([F[i] for i in order[:8]]), best_f), flush=True)
+        if best_f >= 999.5:
+            break
+    print('    "%s": (%s),' % (kind, ", ".join("%.8g" % v for v in best)))
+
+
+if __name__ == "__main__":
+    main()
