@@ -430,15 +430,20 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real gm = g1 < g2 ? g1 : g2;
         if (g3 < gm) gm = g3;
         int touch = decide(0, d < 0 && d > (real)-0.10 && rho2 < g_stone_r * g_stone_r, gm);
+        /* a foot is on the target when a corner touches stone n -- whichever stone carries that corner (with a contact radius
+         * beyond half the stone spacing the discs of neighbouring stones overlap, PHYSICS.md 3.3) */
+        if (touch && sl == 1) fr->foot_on_target[f] = 1;
         /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
-         * forced against d >= 0) */
-        int wins = decide(0, !c->active || d < best, (touch && c->active) ? d - best : FAR_MARGIN);
+         * forced against d >= 0); an exact tie between COPLANAR stones goes to the lower slot and is not a decision -- either
+         * winner gives the same normal and the same depth */
+        int coplanar_tie = c->active && d == best && nrm[0] == c->n[0] && nrm[1] == c->n[1] && nrm[2] == c->n[2];
+        int wins = decide(0, !c->active || d < best, (touch && c->active && !coplanar_tie) ? d - best : FAR_MARGIN);
         if (touch && wins) {
           best = d; c->active = 1; c->stone = idx[sl]; c->pen = -d;
           c->n[0] = nrm[0]; c->n[1] = nrm[1]; c->n[2] = nrm[2];
         }
       }
-      if (c->active) { fr->foot_contact[f] = 1; if (c->stone == n) fr->foot_on_target[f] = 1; }
+      if (c->active) fr->foot_contact[f] = 1;
     }
   }
 }
@@ -522,12 +527,12 @@ static void contact_solve(const sso_model* M, const work* w, const real* qd_free
     if (bn[k] > VCORR_MAX) bn[k] = VCORR_MAX;
     c->lam[0] = c->lam[1] = c->lam[2] = 0;
   }
-  /* warm start: a corner that touched the same stone in the previous substep of this control step starts from
-   * that substep's impulses (applied to the twists before the first sweep) */
+  /* warm start: a corner that was in contact in the previous substep of this control step starts from that substep's
+   * impulses (applied to the twists before the first sweep) */
   if (g_pgs_warm)
     for (int k = 0; k < 8; ++k) {
       contact* c = &ct[k];
-      if (!c->active || ws->stone[k] != c->stone) continue;
+      if (!c->active || ws->stone[k] < 0) continue;
       int f = k / 4;
       for (int d = 0; d < 3; ++d) {
         c->lam[d] = ws->lam[k][d];

@@ -183,7 +183,7 @@ struct FootReport {   // this lane's foot
 
 struct Warm {      // this lane's foot: the contact impulses at the end of the previous substep of this control step
   float lam[4][3];
-  int key;          // bit k: corner k was in contact; bits 4 + 2k, 5 + 2k: on which stone slot (key = 0: nothing to start from)
+  int key;          // bit k: corner k was in contact (key = 0: nothing to start from)
 };
 SSD void warm_clear(Warm& w) {
 #pragma unroll
@@ -579,15 +579,17 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
         float d = dx * sn_[sl][0] + dy * sn_[sl][1] + dz * sn_[sl][2];
         float lx = dx - d * sn_[sl][0], ly = dy - d * sn_[sl][1], lz = dz - d * sn_[sl][2];
         float rho2 = lx * lx + ly * ly + lz * lz;
-        bool hit = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2) && (d < best);
-        if (hit) { best = d; slot = sl; }
+        const bool touch = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2);
+        // on the target = a corner within stone n's contact disc, whichever stone carries the corner (neighbouring discs overlap
+        // once the contact radius exceeds half the stone spacing, PHYSICS.md 3.3)
+        if (touch && sl == 1) fr.on_target = 1;
+        if (touch && d < best) { best = d; slot = sl; }      // the deeper stone wins, an exact tie goes to the lower slot
       }
       o.pen[k] = -best;
       if (slot >= 0) {
         active |= 1 << k;
         cslot |= slot << (2 * k);
         fr.contact = 1;
-        if (slot == 1) fr.on_target = 1;
       }
     });
   }
@@ -1292,15 +1294,15 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
       SS_PROF(8);
       // projected Gauss-Seidel in packed f32 (v_pk_fma_f32: two lanes of the 6-vectors per instruction): the foot twist,
       // the rows y = Lambda w and w, the sweep's wrench and the G / T columns are held as three float pairs each
-      // warm start (PHYSICS.md 3.4): a corner that touched the SAME stone in the previous substep of this control step starts from
-      // that substep's impulses; every other corner from zero
+      // warm start (PHYSICS.md 3.4): a corner that was in contact in the previous substep of this control step starts from that
+      // substep's impulses; every other corner from zero
       if constexpr (HELPERS == 0) load_warm();
       float lam[4][3];
-      const int key = active | (det.cslot << 4);
+      const int key = active;
       int warm_any = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool w = kPgsWarm && (((active & wkey_prev) >> k) & 1) && ((((wkey_prev ^ key) >> (4 + 2 * k)) & 3) == 0);
+        const bool w = kPgsWarm && (((active & wkey_prev) >> k) & 1);
         warm_any |= w ? 1 : 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) lam[k][d] = w ? wlam_prev[k][d] : 0.f;

@@ -1,5 +1,6 @@
 """A committed stabilising controller for closed-loop tests (own gains, found by a cross-entropy search against the
-fp32 CPU oracle; nothing here comes from the reference or its shipped policies).
+fp32 CPU oracle -- tools/tune_balance_controller.py, re-run in round 5 for the identified robots; nothing here comes from the
+reference or its shipped policies).
 
 Joint-space PD to the nominal pose plus torso feedback: ankle-y and hip-y torques on (pitch - lean, forward speed),
 hip-x on (roll, lateral speed), abdomen-x on roll.  Inputs are taken from the 60-float observation only
@@ -11,8 +12,8 @@ from steppingstone_amd import model
 
 #           kp      kd      ankle_p ankle_v hip_p   hip_v   roll_p  roll_v  abd_r   lean    [x_pos  y_pos]
 GAINS = {
-    "walker3d": (2.6554768, 0.044610441, 2.7720696, 1.0294094, 0.33246774, 0.024275567, 0.71981069, 0.64566949, 0.17485336, 0.013770056, 2.5732925, 0.80477416),
-    "mike": (2.42626432, 0.00591566469, 1.06855227, 0.908346373, 1.10546228, 0.371718653, 6.20197915, 0.880407986, 1.48045742, 0.0384706459),
+    "walker3d": (1.6440114, 0.042941625, 0.79333964, 0.83468977, 0.2894796, 0.11817811, 0.48873134, 0.59796555, 0.27787879, 0.0060598901, 3.4924381, 0.59095955),
+    "mike": (3.1731444, 0.0089635373, 0.72874725, 0.77964025, 2.3102897, 0.36061148, 6.5243057, 0.094869488, 2.9437466, 0.084345045),
 }
 
 

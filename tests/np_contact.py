@@ -10,7 +10,7 @@ Different construction from the oracle on purpose:
     (`v = w . (V* + L_ff W_f + L_fg W_g(previous sweep))`), which is the same iteration written in impulse space.
 Both follow the same specification: 5 sweeps, Gauss-Seidel inside a foot (corners 0..3, normal then t1, t2), Jacobi
 between the two feet, lambda_n >= 0, friction pyramid |lambda_t| <= mu lambda_n, Baumgarte term; warm start: a corner that
-touched the same stone in the previous substep of the same control step starts from that substep's impulses (here: the
+was in contact in the previous substep of the same control step starts from that substep's impulses (here: the
 accumulated wrenches start from sum w lambda_0; the oracle applies y lambda_0 to the foot twists)."""
 import numpy as np
 
@@ -62,14 +62,18 @@ def detect(m, pos, quat, q, terrain, n):
             if f == 1:
                 r[1] = -r[1]
             P = p[b] + R[b] @ r
-            best, hit = 0.0, None
-            for si in idx:
+            best, hit, on_target = 0.0, None, False
+            for sl, si in enumerate(idx):
                 st = terrain[si]
                 nrm = stone_normal(st)
                 d = float((P - st[:3]) @ nrm)
                 rho = np.linalg.norm((P - st[:3]) - d * nrm)
-                if -REACH < d < 0 and rho < STONE_R and d < best:
+                touch = -REACH < d < 0 and rho < STONE_R
+                on_target = on_target or (touch and sl == 1)       # touches stone n, whichever stone carries the corner
+                if touch and d < best:                             # the deeper stone wins; ties go to the lower slot
                     best, hit = d, dict(r=r, stone=si, n=nrm, pen=-d, foot=f, Rf=R[b])
+            if hit is not None:
+                hit["on_target"] = on_target
             out.append(hit)
     return out
 
@@ -141,8 +145,8 @@ def substep(m, st, tau_m, sweeps=SWEEPS, warm=None):
     out["warm"] = (np.zeros((8, 3)), [-1] * 8)
     if any(c is not None for c in contacts):
         lam0 = None
-        if warm is not None:                  # a corner keeps its impulses only if it touched the SAME stone in the previous substep
-            lam0 = np.array([warm[0][k] if (c is not None and warm[1][k] == c["stone"]) else np.zeros(3) for k, c in enumerate(contacts)])
+        if warm is not None:                  # a corner keeps its impulses if it was in contact in the previous substep
+            lam0 = np.array([warm[0][k] if (c is not None and warm[1][k] >= 0) else np.zeros(3) for k, c in enumerate(contacts)])
         lam, wrench, Wr, bn = pgs(Li, Vfree, contacts, m["friction"], sweeps, lam0)
         dv = Hinv_Jt @ wrench.reshape(12)
         out.update(lam=lam, wrench=wrench, W=Wr, bn=bn)

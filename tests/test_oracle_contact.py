@@ -71,7 +71,7 @@ def test_contact_stage_matches_independent_numpy(kind):
             continue
         count[nf] += 1
         if warm is not None:
-            kept = [k for k, c in enumerate(ref["contacts"]) if c is not None and warm[1][k] == c["stone"]]
+            kept = [k for k, c in enumerate(ref["contacts"]) if c is not None and warm[1][k] >= 0]
             warm_corners += len(kept)
             warm_rows += sum(int(np.abs(warm[0][k]).max() > 0) for k in kept)
         one.set_state(st[None])

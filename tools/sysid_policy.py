@@ -112,6 +112,8 @@ def overrides_of(kind, x, S):
             mid = 0.5 * (lo + hi)
             lo, hi = mid - 5.0, mid + 5.0
         ov["range." + t] = (lo, hi)
+    if FIXED_STONE_RADIUS:
+        ov["env.stone_radius"] = FIXED_STONE_RADIUS     # an ENV constant: one value for both robots in the final stages
     sole[2] = max(sole[2], 0.015)
     sole[0] = max(sole[0], sole[1] + 0.04)
     ov["sole"] = tuple(sole)
@@ -202,6 +204,7 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     return score
 
 
+FIXED_STONE_RADIUS = 0.0 # --stone-radius in a search: the coordinate is frozen at this value
 SPEC_STONE_RADIUS = 0.25 # what a model without an "env.stone_radius" override is evaluated with
 CURRICULA = [0]          # --curricula: terrains averaged in the score (0 = flat, 5 = the full yaw x pitch grid)
 PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of each coordinate's std): pulls numbers the score does not need back
@@ -281,7 +284,9 @@ def main():
     ap.add_argument("--prior", type=float, default=0.0, help="L2 pull towards the specification's defaults (per mean squared std)")
     ap.add_argument("--sigma0", type=float, default=0.0)
     args = ap.parse_args()
-    global CURRICULA, PRIOR
+    global CURRICULA, PRIOR, FIXED_STONE_RADIUS
+    if args.stone_radius and not (args.emit or args.evaluate or args.ablate):
+        FIXED_STONE_RADIUS = args.stone_radius
     CURRICULA = [int(c) for c in args.curricula.split(",")]
     PRIOR = args.prior
     S = space()
