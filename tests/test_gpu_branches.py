@@ -93,7 +93,7 @@ def test_last_stone_and_target_bonus_on_hip(env_id, kind):
         assert np.array_equal(sg[same][:, INT_FIELDS], so[same][:, INT_FIELDS])
         assert np.array_equal(raw[same, 4], io["update_terrain"][same]) and np.array_equal(raw[same, 3], io["steps_reached"][same])
         plain = r["category"] == 0
-        assert np.abs(og - r["oracle"]["obs"])[plain].max() <= 1e-4
+        assert not plain.any() or np.abs(og - r["oracle"]["obs"])[plain].max() <= 1e-4
         saw_advance |= io["update_terrain"].astype(bool)
         if t == 0:
             # torso within 0.15 m of the last stone: +2 tall bonus +2 target bonus minus small costs

@@ -14,8 +14,9 @@ from steppingstone_amd.envs import SteppingStoneVecEnv, kind_of
 torch = pytest.importorskip("torch")
 
 # (env id, kind, envs, steps, mean stones beyond the start >=, median >=) on flat terrain
-CASES = [("Walker3DStepperEnv-v0", "walker3d", 32, 700, 8.0, 12.0),
-         ("MikeStepperEnv-v0", "mike", 32, 700, 4.0, 5.0)]
+# (measured at adoption: Walker3D 18.0 / 18, Mike 17.5 / 18 in the oracle; a regression guard, set well below)
+CASES = [("Walker3DStepperEnv-v0", "walker3d", 32, 700, 14.0, 17.0),
+         ("MikeStepperEnv-v0", "mike", 32, 700, 12.0, 15.0)]
 
 
 @pytest.mark.parametrize("env_id,kind,n,steps,mean_min,median_min", CASES)

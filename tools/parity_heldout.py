@@ -75,7 +75,7 @@ def judged_cell(env_id, kind, n, seed, offset, cur, steps, policy, rollout_launc
         if d.any():
             walked += info["steps_reached"][d].tolist()
     st = J.o32.get_state()
-    res = []
+    res, dumps = [], []
     for t in range(burn, burn + steps):
         a = policy_actions(J.o32.get_obs()) if policy is not None else J.o32.random_actions(t_base + t)
         g.set_state(st)
@@ -87,10 +87,14 @@ def judged_cell(env_id, kind, n, seed, offset, cur, steps, policy, rollout_launc
         raw = g._info.cpu().numpy()
         r = J.judge(st, a, og, rg, np.asarray(dg).astype(bool), sg, raw[:, 2], raw[:, 4])
         res.append(r)
+        for e in np.nonzero(~r["ok"] | r["beyond"])[0]:          # everything needed to replay a miss off-line (tools/heldout_failure_probe.py)
+            dumps.append(dict(step=int(t), env=int(e), global_env_id=int(offset + e), state=np.array(st[e]), action=np.array(a[e]),
+                              hip_obs=np.array(og[e]), hip_rew=float(rg[e]), hip_done=bool(np.asarray(dg)[e]), hip_state=np.array(sg[e]),
+                              hip_info=np.array(raw[e]), failed=bool(not r["ok"][e])))
         st = r["next_state"]
     g.close()
     R, txt = pr.summarize(res)
-    return R, txt, (float(np.mean(walked)) if walked else float("nan"), len(walked))
+    return R, txt, (float(np.mean(walked)) if walked else float("nan"), len(walked)), dumps
 
 
 def main():
@@ -124,8 +128,11 @@ def main():
                 seed, offset = 9001 + 17 * cell_id, 100000 * (cell_id + 1) + 13
                 rollout_launch = (src == "random") and (cell_id % 4 == 0)
                 t0 = time.time()
-                R, txt, walked = judged_cell(env_id, kind, n, seed, offset, cur, args.steps, policies[kind] if src == "policy" else None,
-                                             rollout_launch, t_base=5000 + 1000 * cell_id)
+                R, txt, walked, dumps = judged_cell(env_id, kind, n, seed, offset, cur, args.steps, policies[kind] if src == "policy" else None,
+                                                    rollout_launch, t_base=5000 + 1000 * cell_id)
+                for k, dmp in enumerate(dumps):
+                    np.savez(os.path.splitext(args.json or os.path.join(ROOT, "gpurun_out", "heldout"))[0] + "_miss_cell%d_%d.npz" % (cell_id, k),
+                             kind=kind, env_id=env_id, seed=seed, curriculum=cur, **dmp)
                 c = pa.counts(R)
                 c.update(robot=kind, curriculum=cur, source=src, envs=n, seed=seed, env_id_offset=offset,
                          launch="ss_rollout_random(1)" if rollout_launch else "ss_step", seconds=round(time.time() - t0, 1))
