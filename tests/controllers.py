@@ -11,8 +11,9 @@ import numpy as np
 from steppingstone_amd import model
 
 #           kp      kd      ankle_p ankle_v hip_p   hip_v   roll_p  roll_v  abd_r   lean    [x_pos  y_pos]
+ARM_GAIN = 0.04
 GAINS = {
-    "walker3d": (1.6440114, 0.042941625, 0.79333964, 0.83468977, 0.2894796, 0.11817811, 0.48873134, 0.59796555, 0.27787879, 0.0060598901, 3.4924381, 0.59095955),
+    "walker3d": (1.4132094, 0.050730464, 0.14066191, 0.48762243, 0.40773871, 0.076366938, 0.22644276, 0.89381611, 0.43892566, 0.025935326, 5.950433, 0.80725568),
     "mike": (3.1731444, 0.0089635373, 0.72874725, 0.77964025, 2.3102897, 0.36061148, 6.5243057, 0.094869488, 2.9437466, 0.084345045),
 }
 
@@ -84,6 +85,9 @@ def balance_controller(kind):
         # lightly damped round-5 robot creeps forward for a few hundred steps and tips over its toes
         ex, ey = 0.75 - o[:, 51], -o[:, 50]
         a = kp * (q0[None, :] - q) - kd * qd
+        # the arms only need to hang still: a leg-sized position gain on the shoulders' axial (z) joints -- the arm's own axis, a few
+        # g m^2 of inertia -- is beyond what a 60 Hz loop can hold (it spins them at 30+ rad/s and makes the closed loop chaotic)
+        a[:, 13:21] *= ARM_GAIN
         for j in (7, 12):                        # ankle y
             a[:, j] += ap * (pitch - lean) + av * vx + kx * ex
         for j in (5, 10):                        # hip y

@@ -34,15 +34,19 @@ def survival(args):
     rng = np.random.default_rng(seed)
     alive = np.ones(n, bool)
     life = np.zeros(n)
+    rough, count = 0.0, 0
     for t in range(steps):
         a = np.clip(ctrl(obs) + 0.05 * rng.standard_normal((n, 21)).astype(np.float32), -1, 1).astype(np.float32)
         obs, r, d, info = o.step(a)
         life[alive] += 1
+        if alive.any():
+            rough += float(np.abs(obs[alive, 27:48]).mean())      # 0.1 x joint rates: a controller that chatters keeps the robot up
+            count += 1                                           # too, but makes the closed loop chaotic within a few dozen steps
         alive &= ~d.astype(bool)
         if not alive.any():
             break
     o.close()
-    return float(life.mean())
+    return float(life.mean()) - 400.0 * rough / max(count, 1)
 
 
 def main():
@@ -70,7 +74,7 @@ def main():
                 best, best_f = cand.copy(), f1000
         print("iter %2d: best of generation %.1f (horizon %d), mean of elite %.1f; best so far %.1f of 1000" % (
             it, F[order[0]], steps, np.mean([F[i] for i in order[:8]]), best_f), flush=True)
-        if best_f >= 999.5:
+        if best_f >= 985.0:
             break
     print('    "%s": (%s),' % (kind, ", ".join("%.8g" % v for v in best)))
 
