@@ -1,0 +1,27 @@
+"""The generated robot tables (steppingstone_amd/csrc/ss_model_tables.hpp for the kernels, oracle/ss_model_tables.h for the oracle) must be
+what tools/gen_model_tables.py produces from steppingstone_amd/model.py + identified_*.json RIGHT NOW: since round 5 the specification's
+numbers live in data files, and a stale table would silently put the kernels, the oracle and the numpy restatements on different robots."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_committed_tables_equal_the_generator_output():
+    import gen_model_tables as gen
+    from steppingstone_amd import model
+    for kind, _, _ in gen.KINDS:
+        gen.assert_mirror_symmetric(model.build(kind))
+    assert open(os.path.join(ROOT, "steppingstone_amd", "csrc", "ss_model_tables.hpp")).read() == gen.gen_hpp()
+    assert open(os.path.join(ROOT, "oracle", "ss_model_tables.h")).read() == gen.gen_h()
+
+
+def test_identified_numbers_are_what_the_specification_evaluates():
+    from steppingstone_amd import model
+    for kind in ("walker3d", "mike"):
+        ident = model.identified(kind)
+        assert ident, "steppingstone_amd/identified_%s.json is missing" % kind
+        m, prior = model.build(kind), model.build(kind, use_identified=False)
+        assert abs(m["friction"] - ident["friction"]) < 1e-12 and m["mass"].sum() != prior["mass"].sum()
+    assert model.env_constants()["stone_contact_radius"] == 0.45 and model.env_constants(use_identified=False)["stone_contact_radius"] == 0.25
