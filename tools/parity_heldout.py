@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--policy-dir", default=os.path.join(ROOT, "gpurun_out", "heldout_policies"))
     ap.add_argument("--train-updates", type=int, default=100)
     ap.add_argument("--json", default="")
+    ap.add_argument("--seed-base", type=int, default=9001, help="another value = another independent sample (seeds, env ids, policy noise)")
     args = ap.parse_args()
     import torch
     from steppingstone_amd import ppo
@@ -125,11 +126,11 @@ def main():
         for cur in (0, 3, 5):
             for src in ("random", "policy"):
                 n = 3000 if (cell_id % 2 == 0) else 5056
-                seed, offset = 9001 + 17 * cell_id, 100000 * (cell_id + 1) + 13
+                seed, offset = args.seed_base + 17 * cell_id, 100000 * (cell_id + 1) + 13 + (args.seed_base - 9001) * 1000
                 rollout_launch = (src == "random") and (cell_id % 4 == 0)
                 t0 = time.time()
                 R, txt, walked, dumps = judged_cell(env_id, kind, n, seed, offset, cur, args.steps, policies[kind] if src == "policy" else None,
-                                                    rollout_launch, t_base=5000 + 1000 * cell_id)
+                                                    rollout_launch, t_base=5000 + 1000 * cell_id + (args.seed_base - 9001) * 7)
                 for k, dmp in enumerate(dumps):
                     np.savez(os.path.splitext(args.json or os.path.join(ROOT, "gpurun_out", "heldout"))[0] + "_miss_cell%d_%d.npz" % (cell_id, k),
                              kind=kind, env_id=env_id, seed=seed, curriculum=cur, **dmp)
