@@ -5,6 +5,17 @@ FROZEN for round 5 (tests/parity_rule.lock holds the SHA-256 of this file; tests
 constants below were calibrated on rounds 3-4's kernels and amended four times in round 4 after misses, so from here on a miss is
 fixed in the kernel or reported as a miss -- not absorbed by the rule.  Held-out validation: tools/parity_heldout.py.
 
+VERSION 2 (re-locked once, at the end of round 5, in a commit of its own).  Version 1 (sha256 e1a62ad8...) was validated on three
+held-out samples of 1 063 392 GPU env-steps each: 1, 0 and 3 failures (profiles/r05_v1b / v1c / v1d_parity_heldout.*).  All four were
+diagnosed off line (tools/heldout_failure_probe.py, profiles/*_miss_diagnosis.txt) as ONE limitation of the SEARCH, not of a bound: two
+sole corners of a standing Mike sat on their touch threshold through all four substeps = 8 near-threshold decisions; version 1 listed
+the first 6 (oracle_lib.NEAR_CAP) and so never inverted the one of the fourth substep that the kernel had taken -- with it inverted
+the oracle equals the kernel to 1.2e-7, integers included.  Version 2 changes the search capacity and nothing else: NEAR_LIST = 16
+decisions listed (4 corners x 4 substeps) and MAX_ALTERNATIVES 24 -> 40 so that the 16 single inversions do not eat the budget of the
+pairs and triples.  No tolerance, factor, ceiling, fraction or depth moved; an env-step with at most 6 near-threshold decisions on
+every branch visited is judged by the oracle runs version 1 made, in the same order.  Version 1's three samples stay on record as
+they came out; version 2 is validated on a FRESH sample (other seeds), not by re-judging those.
+
 Every env-step is bounded.  The acceptance region is NOT the plain max(floor, 8 s) alone: an env-step may sit between 1 x and 2 x its
 sensitivity-scaled bound (`beyond`, counted; callers assert <= 2 in 10 000, never a plain step), and a bound above its ceiling is
 counted as `loose` (asserted < 1 %) rather than capped.  Both escape hatches, the alternative-branch matches and the integer
@@ -63,7 +74,8 @@ POSE_COLS = list(range(0, 7)) + list(range(13, 34))
 VEL_COLS = list(range(7, 13)) + list(range(34, 55))
 ULPS, SENS_FACTOR = 8.0, 8.0
 TAIL_FACTOR, BEYOND_MAX_FRACTION = 2.0, 2e-4   # env-steps between 8 s and 16 s: counted (`beyond`), at most 2 in 10 000 (and never a plain one)
-MAX_DEPTH, MAX_ALTERNATIVES = 3, 24
+MAX_DEPTH, MAX_ALTERNATIVES = 3, 40
+NEAR_LIST = 16                              # near-threshold decisions listed per env-step (version 1: oracle_lib.NEAR_CAP = 6)
 NDYN = 55                                   # pos 3, quat 4, twist 6, q 21, qd 21 of the packed state
 INT_FIELDS = [ol.S_N, ol.S_COUNT, ol.S_ELAPSED, ol.S_CTRLO, ol.S_CTRHI, ol.S_FLAGS]
 
@@ -121,7 +133,7 @@ class StepJudge:
         g_rew = np.asarray(g_rew, np.float64)
         g_int = _ints(np.asarray(g_state), g_done, dict(bad_transition=g_bad, update_terrain=g_upd))
         self.o32.set_state(st)
-        b = self.o32.step_ex(act, tol=NEAR_TOL, record=True)
+        b = self.o32.step_ex(act, tol=NEAR_TOL, record=True, cap=NEAR_LIST)
         so = self.o32.get_state()
         b_int = _ints(so, b["done"], b["info"])
         self.o64.set_state(st64)
@@ -175,7 +187,7 @@ class StepJudge:
     def _branches(self, st, st64, act, b, b_int, near, g_obs, g_rew, g_int, e_rew, ok, matched_e, category, tol_o, g_dyn, e_pose, e_vel,
                   tol_r, tol_p, tol_v):
         """Env-steps with a near-threshold decision: search the alternative branches (module docstring)."""
-        n, cap = self.n, ol.NEAR_CAP
+        n, cap = self.n, NEAR_LIST
         envs = np.nonzero(near)[0]
         # per env: queue of forced sets still to evaluate, the sets seen, the closest integer-exact branch so far
         queue = {e: [(int(i),) for i in b["near"][e, :min(b["nnear"][e], cap)]] for e in envs}
@@ -203,7 +215,7 @@ class StepJudge:
                 nforce[e] = len(S)
                 done_runs[e] += 1
             self.alt.set_state(st)
-            r = self.alt.step_ex(act, tol=NEAR_TOL, force=force, nforce=nforce)
+            r = self.alt.step_ex(act, tol=NEAR_TOL, cap=cap, force=force, nforce=nforce)
             a_state = self.alt.get_state()
             a_int = _ints(a_state, r["done"], r["info"])
             for e in todo:
@@ -238,7 +250,7 @@ class StepJudge:
                 force[e, :len(S)] = S
                 nforce[e] = len(S)
             self.alt.set_state(st)
-            ra = self.alt.step_ex(act, force=force, nforce=nforce, record=True)
+            ra = self.alt.step_ex(act, cap=cap, force=force, nforce=nforce, record=True)
             ra_state = self.alt.get_state()
             self.o64.set_state(st64)
             r6 = self.o64.step_ex(act, replay=ra["trace"])

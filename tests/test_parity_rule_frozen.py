@@ -13,8 +13,9 @@ def test_parity_rule_is_the_locked_one():
     assert have == want, "tests/parity_rule.py was edited after it was frozen"
 
 
-def test_frozen_constants_are_the_round_4_values():
+def test_frozen_constants_are_the_round_4_values_and_the_search_capacity_is_version_2s():
     import parity_rule as pr
     assert (pr.OBS_TOL, pr.REW_TOL, pr.NEAR_TOL, pr.POSE_TOL, pr.VEL_TOL) == (1e-4, 1e-4, 1e-5, 1e-4, 1e-3)
     assert (pr.OBS_CEIL, pr.POSE_CEIL, pr.VEL_CEIL, pr.REW_CEIL, pr.LOOSE_MAX_FRACTION) == (5e-3, 5e-3, 5e-2, 5e-2, 1e-2)
-    assert (pr.ULPS, pr.SENS_FACTOR, pr.TAIL_FACTOR, pr.BEYOND_MAX_FRACTION, pr.MAX_DEPTH, pr.MAX_ALTERNATIVES) == (8.0, 8.0, 2.0, 2e-4, 3, 24)
+    assert (pr.ULPS, pr.SENS_FACTOR, pr.TAIL_FACTOR, pr.BEYOND_MAX_FRACTION, pr.MAX_DEPTH) == (8.0, 8.0, 2.0, 2e-4, 3)
+    assert (pr.NEAR_LIST, pr.MAX_ALTERNATIVES) == (16, 40)          # version 2: the search's capacity, the only change (module docstring)

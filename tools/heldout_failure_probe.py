@@ -1,7 +1,7 @@
 """Off-line diagnosis of a miss of the frozen parity rule (tools/parity_heldout.py dumps every failed / beyond env-step as
 <json stem>_miss_cell<c>_<k>.npz: injected state, action, and everything the HIP kernel returned).
 
-The frozen rule (tests/parity_rule.py) lists at most oracle_lib.NEAR_CAP = 6 near-threshold decisions of an env-step and searches
+Version 1 of the frozen rule (tests/parity_rule.py; version 2 lists NEAR_LIST = 16) listed at most 6 near-threshold decisions of an env-step and searched
 subsets of at most MAX_DEPTH = 3 of them.  This tool lifts both limits for ONE env-step: it lists every decision within NEAR_TOL of its
 threshold and tries every subset, and it re-runs the step with the base height nudged by +-1e-5 .. 4e-5 m (a knife-edge state decides
 itself one way or the other; the kernel compiled for the host -- tests/host_lib.py -- must then agree with the oracle as it runs).
@@ -36,7 +36,7 @@ gi = pr._ints(D["hip_state"][None], np.array([D["hip_done"]]), dict(bad_transiti
 bi = pr._ints(o.get_state(), b["done"], b["info"])
 print("oracle as it ran: |obs - kernel| %.2e, integers equal %s" % (np.abs(b["obs"][0] - D["hip_obs"]).max(), bool((gi == bi).all())))
 print("decisions within %.0e of their threshold: %d -> %s   (the rule lists at most %d of them and inverts at most %d at a time; decision index = "
-      "90 x substep + 42 joint-limit switches + 6 x sole corner + 2 x stone slot + {0: touches, 1: wins})" % (pr.NEAR_TOL, len(near), near, 6, pr.MAX_DEPTH))
+      "90 x substep + 42 joint-limit switches + 6 x sole corner + 2 x stone slot + {0: touches, 1: wins})" % (pr.NEAR_TOL, len(near), near, pr.NEAR_LIST, pr.MAX_DEPTH))
 best, tried = (np.inf, None), 0
 for k in range(0, min(len(near), 10) + 1):
     for S in itertools.combinations(near, k):
@@ -51,7 +51,7 @@ for k in range(0, min(len(near), 10) + 1):
             best = (e, S)
 print("every subset of them inverted (%d oracle runs): the kernel's result is the oracle's with %s inverted -- integers equal, |obs - kernel| %.2e%s" % (
     tried, best[1], best[0], "" if best[1] is None or all(i in near[:6] for i in best[1]) else
-    "; decision(s) %s are beyond the rule's list of 6, so the rule never tried them" % [i for i in best[1] if i not in near[:6]]))
+    "; decision(s) %s are beyond the list of 6 of rule version 1, which never tried them (version 2 lists %d)" % ([i for i in best[1] if i not in near[:6]], pr.NEAR_LIST)))
 out, oh, rh, dh, ih = hl.step(ol.KIND[kind], st, act, seed=seed, curriculum=cur)
 print("the kernel source compiled for the host on the same state: |obs - GPU| %.2e" % np.abs(oh[0] - D["hip_obs"]).max())
 for dz in (-4e-5, -2e-5, -1e-5, 1e-5, 2e-5, 4e-5):
