@@ -15,7 +15,14 @@ import parity_rule as pr
 # bound at most 2 x the floor and the 90 % quantile at most 1e-3 (rounds 3-4 samples: 1.0e-4 / 3.7e-4; round 5: 1.04e-4 / 3.9e-4).
 # The plain fraction stays the headline every caller prints (counts()["held_to_flat_1e4"]).
 BOUND_MEDIAN_MAX, BOUND_Q90_MAX = 2e-4, 1e-3
-INT_EXCUSED_MAX_FRACTION = 1e-3
+# ROUND 6, with version 3 of the rule (a narrowing to what 6.38 M held-out env-steps of round 5 support; set before any new sample):
+#   * the 99.9 % quantile of err / bound: < 0.2 (round 5 asserted < 0.5; measured 0.056 - 0.13 on the six held-out runs);
+#   * `beyond` and `int_excused` must be ZERO (version 3 turns both into failures of the rule itself; asserted here as well);
+#   * a hard floor on the plain fraction: at least 30 % of a sample's env-steps are held to the flat 1e-4.  Measured: 44-54 %
+#     on random-action cells, 35-86 % on policy-driven cells, 45 % / 58 % in the driver's smoke.  It is a statement about the
+#     specification on the sample (see above), so it guards the rule against drifting, not the kernel.
+Q999_ERR_OVER_BOUND_MAX = 0.2
+PLAIN_MIN_FRACTION = 0.30
 
 
 def counts(R):
@@ -37,14 +44,15 @@ def assert_judged(R, txt, label, log=print):
     assert R["ok"].all(), "%d env-steps outside their bound" % (~R["ok"]).sum()
     plain = R["category"] == 0
     assert plain.any() and R["matched_e"][plain].max() <= pr.OBS_TOL          # the north-star's 1e-4 wherever 8 s <= 1e-4
-    assert R["int_excused"].mean() < INT_EXCUSED_MAX_FRACTION
+    assert plain.mean() >= PLAIN_MIN_FRACTION, "only %.1f %% of the env-steps are held to the flat 1e-4" % (100 * plain.mean())
+    assert R["int_excused"].sum() == 0                                         # version 3: an unstable probe excuses nothing
     assert np.quantile(R["tol"], 0.5) <= BOUND_MEDIAN_MAX and np.quantile(R["tol"], 0.9) <= BOUND_Q90_MAX, (
         "bounds drifted away from the floor: median %.2e, 90 %% %.2e" % (np.quantile(R["tol"], 0.5), np.quantile(R["tol"], 0.9)))
     assert R["loose"].mean() <= max(pr.LOOSE_MAX_FRACTION, 2.0 / R["loose"].size)      # bounds beyond their ceilings stay rare
-    # the tail of err / bound: at most 2 in 10 000 env-steps (1 in a small sample) between 1 x and 2 x their bound, none of them a plain
-    # step (asserted above), and the bulk far inside: 99.9 % of env-steps below half their bound (measured 0.10 - 0.13)
-    assert R["beyond"].sum() <= max(1, int(pr.BEYOND_MAX_FRACTION * R["beyond"].size)), "%d env-steps beyond their bound" % R["beyond"].sum()
-    assert np.quantile(R["matched_e"] / R["tol"], 0.999) < 0.5
+    # the tail of err / bound: version 3 has none (outside the bound is a failure, asserted above) and the bulk sits far inside:
+    # 99.9 % of env-steps below a fifth of their bound (measured 0.056 - 0.13)
+    assert R["beyond"].sum() == 0, "%d env-steps beyond their bound" % R["beyond"].sum()
+    assert np.quantile(R["matched_e"] / R["tol"], 0.999) < Q999_ERR_OVER_BOUND_MAX
     # all env-steps, against the oracle as it ran: 99 % within the north-star's 1e-4 (measured: 99 % within 2e-5), at most 0.5 % beyond it
     assert np.quantile(R["e_obs"], 0.99) < 1e-4 and (R["e_obs"] > 1e-4).mean() < 5e-3
     # ... and against the fp64 evaluation the kernel is no noisier than the CPU's own fp32 build (which also leaves 1e-4 on ~0.16 %)

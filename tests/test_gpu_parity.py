@@ -10,9 +10,11 @@ tests/parity_rule.lock -- and the thresholds every caller asserts are tests/pari
     max(1e-3, 8 s_vel), where 1e-4 is the north-star's per-step bound and s is the measured first-order response of the fp64 oracle
     to an 8-ulp error in each of that step's 55 dynamic state inputs (summed).  An env-step whose oracle evaluation has a discrete
     decision within 1e-5 of its threshold must match the oracle re-evaluated on one of the alternative branches (integers exactly).
-    The rule's escape hatches, all counted and asserted rare by parity_assert.assert_judged: an env-step between 1 x and 2 x its
-    sensitivity-scaled bound (`beyond`, <= 2 in 10 000, never a plain step); a bound above its ceiling (`loose`, < 1 %); an integer
-    mismatch where the 8-ulp probe itself changes an integer outcome (< 0.1 %); at most half of the env-steps on a scaled bound;
+    Version 3 of the rule (round 6): outside max(floor, 8 s) is a FAILURE (no 1 x - 2 x tail) and an integer mismatch is never
+    excused by an unstable probe.  What parity_assert.assert_judged asserts about a sample on top of "no failure": the plain env-steps
+    within 1e-4; at least 30 % of the env-steps plain (held to the flat 1e-4); the bounds' median <= 2e-4 and 90 % quantile <= 1e-3;
+    a bound above its ceiling (`loose`) on < 1 % of the env-steps; `beyond` == 0 and `int_excused` == 0; the 99.9 % quantile of
+    err / bound < 0.2; 99 % of all env-steps within 1e-4 of the oracle as it ran;
   * launch shapes and kernel variants of the SAME step are compared bitwise (array_equal), never with a tolerance;
   * free-running drift is chaotic (contacts make/break): characterised against the fp64 build, see
     tests/test_gpu_branches.py::test_closed_loop_1000_step_drift.
