@@ -605,8 +605,8 @@ def main():
 def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
     """BASELINE.json configs[4] as it words it: MikeStepperEnv-v0, curriculum sampler on, 4096 envs per MI355X, the loop of
     playground/train.py:363-521 (32-step rollouts, GAE, 10 PPO epochs of minibatch 1024, exponential lr decay, fixed-order
-    curriculum gate) with the actor / critic on PyTorch-ROCm (learner "torch": autograd + torch.optim.Adam) as THE row, and the
-    opt-in hand-written learner kernels (learner "fused") as a labelled side row.  frames = env-steps collected; the value is
+    curriculum gate) with the actor / critic on PyTorch-ROCm (autograd + torch.optim.Adam, steppingstone_amd.ppo.PPO).
+    frames = env-steps collected; the value is
     steady-state frames/s over the updates after the first three (graph capture / allocator warm-up), the whole-run figure
     beside it.  One JSON line from rank 0."""
     from steppingstone_amd import ppo
@@ -617,14 +617,7 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
     # of minibatches per epoch instead (train.py:63: 40000 // 1024 = 39; the nearest divisor of the rollout is 32 -> minibatch 4096).
     MB_SCALED = max(MB, (T * n_local) // 32)
     rows = {}
-    for key, learner, mb in (("torch", "torch", MB), ("torch_scaled", "torch", MB_SCALED), ("fused", "fused", MB)):
-        if learner == "fused" and world > 1 and os.environ.get("SS_BENCH_TEST_TRANSPORT"):
-            continue
-        if learner == "fused":        # outside SURVEY section 8, opt-in: the side row exists only where its library has been built
-            from steppingstone_amd import fused_ppo
-            if not os.path.exists(fused_ppo.LIB_PATH):
-                rows[key] = {"value": None, "note": "opt-in fused learner not built (SS_BUILD_LEARNER=1 python -m steppingstone_amd.build)"}
-                continue
+    for key, mb in (("torch", MB), ("torch_scaled", MB_SCALED)):
         PHASE["name"] = "ppo row %s (minibatch %d)" % (key, mb)
         envs = SteppingStoneVecEnv("MikeStepperEnv-v0", n_local, seed=8, device=dev, env_id_offset=rank * n_local, return_numpy=False)
         stamps = []
@@ -637,7 +630,7 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
             if use_dist:
                 dist.barrier()
             t0 = time.perf_counter()
-            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=mb, use_curriculum=True, log=log, learner=learner)
+            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=mb, use_curriculum=True, log=log)
             torch.cuda.synchronize(dev)
             if use_dist:
                 dist.barrier()
@@ -661,7 +654,7 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
                                       "with its RCCL all-reduce captured" % (n_local, T, MB),
                           "envs_total": n_local * world, "learner": "torch", "a_step_is": "one PPO update = %d frames" % (T * n_local * world),
                           "parallelism": "data-parallel x%d" % world},
-               "learner_torch": main, "learner_torch_scaled_minibatch": rows.get("torch_scaled"), "learner_fused_side_row": rows.get("fused"),
+               "learner_torch": main, "learner_torch_scaled_minibatch": rows.get("torch_scaled"),
                "minibatch_choice": "value = row A: the reference's minibatch 1024 kept (train.py:62); learner_torch_scaled_minibatch = row B: the "
                                    "reference's ~39 minibatches per epoch kept instead (train.py:63), i.e. minibatch %d" % MB_SCALED,
                "note": "random-init weights, synthetic rollouts of the env itself; the value is the torch-learner row A"}

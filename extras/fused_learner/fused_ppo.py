@@ -1,6 +1,6 @@
 """Fused PPO learner: the minibatch loop body of algorithms/ppo.py:55-100 (evaluate_actions, clipped surrogate + value
-loss, backward, clip_grad_norm_, Adam) as 15 launches of hand-written gfx950 kernels (steppingstone_amd/csrc/
-ss_learner.hip, include/steppingstone_learner.h; exact-f32 MFMA GEMMs) instead of ~90 launches of generic framework
+loss, backward, clip_grad_norm_, Adam) as 15 launches of hand-written gfx950 kernels (extras/fused_learner/
+ss_learner.hip, steppingstone_learner.h beside it; exact-f32 MFMA GEMMs) instead of ~90 launches of generic framework
 kernels.  Drop-in for steppingstone_amd.ppo.PPO (mirror augmentation and the data-parallel update included):
 
     agent = FusedPPO(actor_critic, ppo_epoch=10, mini_batch_size=1024, lr=3e-4, ...)
@@ -15,8 +15,8 @@ import os
 
 import torch
 
-PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("STEPPINGSTONE_LEARNER_LIB") or os.path.join(PKG, "lib", "libsslearner.so")
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("STEPPINGSTONE_LEARNER_LIB") or os.path.join(HERE, "lib", "libsslearner.so")
 SYMBOLS = ["ssl_last_error", "ssl_num_params", "ssl_create", "ssl_destroy", "ssl_step", "ssl_step_mirror", "ssl_grad", "ssl_apply",
            "ssl_debug_grad"]
 OBS, HID, ACT = 60, 256, 21
@@ -32,7 +32,7 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise FusedLearnerError("libsslearner.so is missing (%s): build it with `python -m steppingstone_amd.build`" % LIB_PATH)
+            raise FusedLearnerError("libsslearner.so is missing (%s): build it with `python extras/fused_learner/build.py`" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
         vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
         lib.ssl_last_error.restype = C.c_char_p
@@ -208,7 +208,7 @@ class FusedPPO:
         With use_graph one hipGraph holds a WHOLE epoch (every minibatch step of it reads its slice of a static permutation
         buffer and adds its losses to a device accumulator), so the host launches ppo_epoch graphs per update instead of
         ppo_epoch x num_mini_batch steps."""
-        from .ppo import _global_mean_std
+        from steppingstone_amd.ppo import _global_mean_std
         adv = roll.returns[:-1] - roll.value_preds[:-1]
         mean, std = _global_mean_std(adv)                   # over every rank's transitions
         adv = (adv - mean) / (std + 1e-5)

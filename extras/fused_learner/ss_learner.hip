@@ -26,7 +26,7 @@
 #include <cstring>
 #include <string>
 
-#include "../../include/steppingstone_learner.h"
+#include "steppingstone_learner.h"
 
 namespace {
 

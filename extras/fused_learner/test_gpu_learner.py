@@ -1,4 +1,4 @@
-"""Fused PPO learner (steppingstone_amd/fused_ppo.py -> libsslearner.so, MFMA f32 kernels) against torch autograd and
+"""Fused PPO learner (extras/fused_learner/fused_ppo.py -> lib/libsslearner.so, MFMA f32 kernels) against torch autograd and
 against the reference's own PPO.update golden vectors (tests/golden/harness_golden.npz).  `pytest -m gpu`."""
 import numpy as np
 import pytest
@@ -6,11 +6,16 @@ import pytest
 import os
 
 torch = pytest.importorskip("torch")
-# OUT OF SURVEY section 8's SCOPE (the PPO learner is SURVEY section 2 #5-#7, "no custom kernel warranted"): frozen and opt-in.  The library
-# is built only by `SS_BUILD_LEARNER=1 python -m steppingstone_amd.build` (not by __graft_entry__.build()), and these tests run only
-# where it has been built -- the default GPU suite spends its time on the step() path.
-_LEARNER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "steppingstone_amd", "lib", "libsslearner.so")
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(_LEARNER), reason="opt-in fused learner not built (SS_BUILD_LEARNER=1)")]
+# OUT OF SURVEY section 8's SCOPE (the PPO learner is SURVEY section 2 #5-#7, "no custom kernel warranted"): frozen, and since round 6
+# OUTSIDE the product package and outside tests/ -- `python extras/fused_learner/build.py && python -m pytest extras/fused_learner -m gpu`.
+import sys
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+for _p in (_HERE, _ROOT, os.path.join(_ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+_LEARNER = os.path.join(_HERE, "lib", "libsslearner.so")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(_LEARNER), reason="fused learner not built (python extras/fused_learner/build.py)")]
 
 
 def _batch(R, dev, seed=0):
@@ -37,7 +42,8 @@ def _torch_reference(ac, data, idx, clip=0.2, lr=3e-4, eps=1e-5, max_norm=2.0):
 
 @pytest.mark.parametrize("E,B", [(1, 1024), (2, 512), (3, 96)])
 def test_fused_step_matches_autograd_and_adam(E, B):
-    from steppingstone_amd import fused_ppo, ppo
+    import fused_ppo
+    from steppingstone_amd import ppo
     dev = torch.device("cuda:0")
     R = 4096
     torch.manual_seed(1)
@@ -88,7 +94,8 @@ def test_fused_step_matches_autograd_and_adam(E, B):
 def test_fused_update_matches_reference_golden():
     """the reference's PPO.update on the golden batch: three losses and every weight after one Adam step"""
     import os
-    from steppingstone_amd import fused_ppo, ppo
+    import fused_ppo
+    from steppingstone_amd import ppo
     from test_ppo_golden import G, load_reference_weights
     dev = torch.device("cuda:0")
     ac = ppo.ActorCritic(num_ensembles=2)
@@ -110,7 +117,8 @@ def test_fused_update_matches_reference_golden():
 
 
 def test_fused_update_equals_torch_update_over_many_minibatches_and_replays_as_a_graph():
-    from steppingstone_amd import fused_ppo, ppo
+    import fused_ppo
+    from steppingstone_amd import ppo
     dev = torch.device("cuda:0")
     T, N, mb = 8, 512, 1024
     finals = []
@@ -183,7 +191,8 @@ def test_fused_data_parallel_halves_equal_the_global_minibatch():
     leaves on every rank), ssl_apply with 1 / world.  Two 'ranks' are played on one GPU: the result must be the torch step
     (autograd, clip_grad_norm_, Adam) on the concatenated minibatch, and both ranks end with the same weights."""
     import ctypes as C
-    from steppingstone_amd import fused_ppo, ppo
+    import fused_ppo
+    from steppingstone_amd import ppo
     dev = torch.device("cuda:0")
     R, B, E = 4096, 256, 2
     torch.manual_seed(4)

@@ -403,6 +403,27 @@ static void stone_normal(const real* st, real nrm[3]) {
 /* contact radius of a stone (tools/sysid_policy.py's terrain study ONLY; the specification's value is STONE_R) */
 static real g_stone_r = STONE_R;
 void sso_debug_set_stone_radius(double r) { g_stone_r = (real)r; }
+/* contact SHAPE study (tools/sysid_policy.py --scan ONLY; never the specification): a > 0 replaces the disc by a rectangle in the
+ * stone's plane, half-length a along the stone's own x axis (R_s e_x, the direction of travel) and half-width b across it */
+static real g_plank_a = 0, g_plank_b = 0;
+void sso_debug_set_plank(double a, double b) { g_plank_a = (real)a; g_plank_b = (real)b; }
+/* stone spacing study (same tool, same status): dr = lo + u * span * curriculum / 5; the specification is 0.65 + u * 0.6 * c / 5 */
+static real g_dr_lo = (real)0.65, g_dr_span = (real)0.6;
+void sso_debug_set_dr(double lo, double span) { g_dr_lo = (real)lo; g_dr_span = (real)span; }
+/* on-target rule study: 1 = a foot is on the target only through a corner that stone n CARRIES (wins), 0 = the specification's rule */
+static int g_target_carried = 0;
+static real g_target_r = 0;     /* > 0: on-target additionally needs the corner within this radius of stone n's axis (infinite-plane control) */
+void sso_debug_set_target_rule(int carried_only) { g_target_carried = carried_only; }
+void sso_debug_set_target_radius(double r) { g_target_r = (real)r; }
+static int plank_inside(const real* st, const real* l, real* margin) {
+  /* footprint seen from above: the in-plane offset l of the corner from the stone's centre, its horizontal components along / across the
+   * stone's heading phi */
+  real c = r_cos(st[3]), sn = r_sin(st[3]);
+  real u = l[0] * c + l[1] * sn, v = l[1] * c - l[0] * sn;
+  real mu = g_plank_a - (u < 0 ? -u : u), mv = g_plank_b - (v < 0 ? -v : v);
+  *margin = mu < mv ? mu : mv;
+  return mu > 0 && mv > 0;
+}
 static void detect(const sso_model* M, const env_state* s, const work* w, contact ct[8], foot_report* fr) {
   int n = s->n;
   int idx[3] = {n - 1 < 0 ? 0 : n - 1, n, n + 1 > NSTONE - 1 ? NSTONE - 1 : n + 1};
@@ -427,12 +448,14 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real lx = dv[0] - d * nrm[0], ly = dv[1] - d * nrm[1], lz = dv[2] - d * nrm[2];
         real rho2 = lx * lx + ly * ly + lz * lz;
         real g1 = -d, g2 = d + (real)0.10, g3 = g_dec ? g_stone_r - r_sqrt(rho2) : 0;
+        int inside = rho2 < g_stone_r * g_stone_r;
+        if (g_plank_a > 0) { real l3[3] = {lx, ly, lz}; inside = plank_inside(st, l3, &g3); }       /* shape study only */
         real gm = g1 < g2 ? g1 : g2;
         if (g3 < gm) gm = g3;
-        int touch = decide(0, d < 0 && d > (real)-0.10 && rho2 < g_stone_r * g_stone_r, gm);
+        int touch = decide(0, d < 0 && d > (real)-0.10 && inside, gm);
         /* a foot is on the target when a corner touches stone n -- whichever stone carries that corner (with a contact radius
          * beyond half the stone spacing the discs of neighbouring stones overlap, PHYSICS.md 3.3) */
-        if (touch && sl == 1) fr->foot_on_target[f] = 1;
+        if (touch && sl == 1 && !g_target_carried && (g_target_r <= 0 || rho2 < g_target_r * g_target_r)) fr->foot_on_target[f] = 1;
         /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
          * forced against d >= 0); an exact tie between COPLANAR stones goes to the lower slot and is not a decision -- either
          * winner gives the same normal and the same depth */
@@ -444,6 +467,7 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         }
       }
       if (c->active) fr->foot_contact[f] = 1;
+      if (g_target_carried && c->active && c->stone == idx[1]) fr->foot_on_target[f] = 1;
     }
   }
 }
@@ -661,7 +685,7 @@ static real draw_stone(const sso_env* E, int e, env_state* s, int k) {
   env_block(E, e, s, r);
   int cell = sample_cell(s->prob, (float)(r[0] >> 8) * 5.9604644775390625e-08f);
   real ratio = (real)E->curriculum / (real)5;
-  real dr = (real)0.65 + u01(r[1]) * ((real)0.6 * ratio);
+  real dr = g_dr_lo + u01(r[1]) * (g_dr_span * ratio);
   real tilt = (real)15.0 * DEG * ratio;
   real xt = (2 * u01(r[2]) - 1) * tilt, yt = (2 * u01(r[3]) - 1) * tilt;
   place_stone(s, k, yaw_sample(cell / NGRID), pitch_sample(cell % NGRID), dr, xt, yt);

@@ -50,23 +50,6 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-LEARNER_LIB = os.path.join(LIBDIR, "libsslearner.so")
-LEARNER_SRC = os.path.join(CSRC, "ss_learner.hip")
-
-
-def build_learner(force=False, verbose=False):
-    """OPT-IN (SS_BUILD_LEARNER=1 or `python -m steppingstone_amd.build --learner`).  The fused PPO minibatch step (csrc/ss_learner.hip, include/steppingstone_learner.h): MFMA f32 kernels, its own library."""
-    deps = [LEARNER_SRC, os.path.join(PKG, "..", "include", "steppingstone_learner.h")]
-    if not force and os.path.exists(LEARNER_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LEARNER_LIB) for d in deps):
-        return LEARNER_LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", LEARNER_SRC, "-o", LEARNER_LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LEARNER_LIB
-
-
 FUZZ_LIB = os.path.join(LIBDIR, "libsteppingstone_fuzz.so")
 
 
@@ -116,9 +99,6 @@ def build_fuzz(force=False, verbose=False):
 
 
 def build(force=False, verbose=False):
-    # the fused PPO learner is outside SURVEY section 8's path (opt-in, frozen): built only on request
-    if os.environ.get("SS_BUILD_LEARNER", "0") not in ("", "0"):
-        build_learner(force, verbose)
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -127,8 +107,6 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
-    if "--learner" in sys.argv:
-        build_learner(force="--force" in sys.argv, verbose=True)
     if "--fuzz" in sys.argv:
         build_fuzz(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -337,6 +337,8 @@ class SteppingStoneVecEnv:
             raise ValueError("sample_prob must have shape (%d,%d,%d) or (%d,%d), got %s"
                              % (self.num_envs, GRID, GRID, GRID, GRID, probs.shape))
 
+    _warned_set_mirror = False
+
     def create_temp_states(self):
         out = torch.empty((self.num_envs, NCELL, OBS_DIM), dtype=torch.float32, device=self.device)
         self.backend.create_temp_states(out)
@@ -344,7 +346,15 @@ class SteppingStoneVecEnv:
 
     def set_mirror(self, mirror):
         """common/envs_utils.py:588-590.  Accepted for protocol compatibility only: no effect on Walker3D / Mike (their observation has
-        no gait-phase term; include/steppingstone.h ss_set_mirror).  The symmetry itself is get_mirror_indices()."""
+        no gait-phase term; include/steppingstone.h ss_set_mirror).  The symmetry itself is get_mirror_indices().
+        `use_phase_mirror=True` (playground/train.py:48,109-111) is therefore UNSUPPORTED: set_mirror(True) warns once per process
+        instead of silently accepting; the reference's default is False."""
+        if mirror and not SteppingStoneVecEnv._warned_set_mirror:
+            import warnings
+            SteppingStoneVecEnv._warned_set_mirror = True
+            warnings.warn("set_mirror(True): phase mirroring (use_phase_mirror, playground/train.py:48,109) is not supported by this env -- the "
+                          "call is accepted for protocol compatibility and has no effect; use get_mirror_indices() with mirror "
+                          "augmentation (common/envs_utils.py:687-740) instead", RuntimeWarning, stacklevel=2)
         self.backend.set_mirror(bool(mirror))
 
     def set_env_params(self, params_dict):

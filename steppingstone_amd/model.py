@@ -141,7 +141,9 @@ _COMMON = dict(
               "knee": .006, "ankle": .004, "shoulder_x": .004, "shoulder_z": .004, "shoulder_y": .004, "elbow": .003},
     k_lim_per_torque=50.0,        # unilateral limit spring  [N m / rad] per N m of torque limit
     d_lim_per_k=0.02,             # limit damper (active only in violation) [N m s / rad] per N m / rad
-    q0_deg={"hip_y": -12.0, "knee": 24.0, "ankle": -12.0, "elbow": -20.0},     # nominal pose: slight crouch, sole level
+    q0_deg={"hip_x": 0.0, "hip_y": -12.0, "knee": 24.0, "ankle": -12.0, "elbow": -20.0},     # nominal pose: slight crouch, sole level
+    foot_on_sole=False,           # True (round 6): the foot box is DERIVED from the sole rectangle -- bottom face = the four sole corners,
+                                  # height 2 x foot_box_half[2] -- so the contact points always sit on the foot's own geometry
     friction=0.9,
 )
 DEFAULTS = {
@@ -213,6 +215,10 @@ def _humanoid_at_density(P):
     shin = P["shin"] * scale_leg
     ankle_off = shin + P["ankle_gap"]
     fc, fh = P["foot_box_c"], P["foot_box_half"]
+    if P["foot_on_sole"]:
+        xf_, xb_, yh_, zs_ = P["sole"]
+        fh = (0.5 * (xf_ - xb_), yh_, fh[2])
+        fc = (0.5 * (xf_ + xb_), zs_ + fh[2])
     for side, j0 in ((-1.0, 3), (1.0, 8)):
         r[j0] = [0, side * P["hip_y"], P["hip_z"]]   # hip_x origin in pelvis link frame
         g[j0 + 1] = []
@@ -269,7 +275,8 @@ def _humanoid_at_density(P):
 
     # nominal pose: slight crouch so reset starts in a balanced, bent-knee stance
     q0 = np.zeros(NJ)
-    for j0 in (3, 8):
+    for side, j0 in ((1.0, 3), (-1.0, 8)):
+        q0[j0] = side * np.deg2rad(P["q0_deg"]["hip_x"]) + 0.0   # hip_x about the +x axis of the RIGHT side; the left one is its mirror image
         q0[j0 + 2] = np.deg2rad(P["q0_deg"]["hip_y"])   # hip_y (flexion is negative about +y)
         q0[j0 + 3] = np.deg2rad(P["q0_deg"]["knee"])    # knee
         q0[j0 + 4] = np.deg2rad(P["q0_deg"]["ankle"])   # ankle keeps the sole level

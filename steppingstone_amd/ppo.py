@@ -457,7 +457,25 @@ def save_checkpoint(ac, path, **meta):
     needed to rebuild the module -- torch.load(path)["state_dict"] -> ActorCritic(...).load_state_dict."""
     sd = {k: v.detach().cpu() for k, v in ac.state_dict().items()}
     torch.save({"state_dict": sd, "num_ensembles": len(ac.critics), "state_dim": ac.actor.state_dim,
-                "action_dim": ac.actor.action_dim, "policy_convention": policy_convention(), **meta}, path)
+                "action_dim": ac.actor.action_dim, "policy_convention": policy_convention(), "env_fingerprint": env_fingerprint(), **meta}, path)
+
+
+def env_fingerprint():
+    """SHA-256 over the numbers of the env a policy was trained in (both robots' tables as model.build() produces them + the env
+    constants).  Warning-level on load: a policy still means the same joints in a re-identified robot, but it was trained
+    for another body."""
+    import hashlib
+    import numpy as np
+    from . import model
+    h = hashlib.sha256()
+    for kind in ("walker3d", "mike"):
+        m = model.build(kind)
+        for k in sorted(m):
+            if isinstance(m[k], np.ndarray):
+                h.update(k.encode() + np.ascontiguousarray(m[k], np.float32).tobytes())
+        h.update(repr((round(m["friction"], 6), round(m["stand_height"], 6))).encode())
+    h.update(repr(sorted(model.env_constants().items())).encode())
+    return h.hexdigest()
 
 
 def policy_convention():
@@ -470,12 +488,18 @@ def policy_convention():
 
 
 def load_checkpoint(path, device="cpu", allow_convention_mismatch=False):
-    """Refuses a file whose policy convention is missing or differs from this build's (INTEGRATION.md "checkpoints")."""
+    """Refuses a file whose policy convention is missing or differs from this build's (INTEGRATION.md "checkpoints"); WARNS when the
+    convention matches but the file was trained in an env with other numbers (another `env_fingerprint`, or none: a file written
+    before round 6)."""
     ck = torch.load(path, map_location="cpu", weights_only=True)
     have, want = ck.get("policy_convention"), policy_convention()
     if have != want and not allow_convention_mismatch:
         raise ValueError("%s was trained under policy convention %r, this build presents %r: its actions and observations would be "
                          "misread (pass allow_convention_mismatch=True to load it anyway)" % (path, have, want))
+    if ck.get("env_fingerprint") != env_fingerprint():
+        import warnings
+        warnings.warn("%s was trained in an env with other robot / terrain numbers than this build's (env_fingerprint %s): it loads, but "
+                      "expect it to need re-training" % (path, "absent" if ck.get("env_fingerprint") is None else "differs"), RuntimeWarning)
     ac = ActorCritic(ck["state_dim"], ck["action_dim"], num_ensembles=ck["num_ensembles"])
     ac.load_state_dict(ck["state_dict"])
     return ac.to(device), ck
@@ -485,7 +509,7 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
           gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto",
           sampling="none", eval_envs=None, curriculum_threshold=0.85, uniform_every=500000,
           test_envs=None, test_interval=1, logger=None, save_dir="", save_every=1e7, env_name="env",
-          use_specialist=False, learner="torch"):
+          use_specialist=False, agent_factory=None):
     """The training loop of playground/train.py:211-578 on device tensors.  Returns (actor_critic, per-update stats).
 
       use_curriculum   fixed-order curriculum: level += 1 while mean(recent episode returns) > 1000 (train.py:115-118,503-506)
@@ -499,11 +523,10 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
       logger           ConsoleCSVLogger-compatible object (steppingstone_amd.csv_logger): log_epoch(dict) per update
       save_dir         `{env}_latest.pt` every update, `{env}_{frames}.pt` every save_every frames, `{env}_best.pt` on a new
                        best mean return (train.py:523-562)
-      learner          "torch" (default; BASELINE configs[4]: "actor/critic on PyTorch-ROCm"): autograd + torch.optim.Adam
-                       (steppingstone_amd.ppo.PPO); "fused" (opt-in): the minibatch step runs in the hand-written MFMA kernels
-                       of steppingstone_amd.fused_ppo (GPU, minibatch a multiple of 32 that divides the rank's rollout; with
-                       several ranks one all-reduce of the flat gradient sits between its gradient and Adam halves);
-                       "auto": fused when its conditions hold AND its library loads, else torch with a one-line warning
+      agent_factory    None: the learner is steppingstone_amd.ppo.PPO (BASELINE configs[4]: "actor/critic on PyTorch-ROCm": autograd +
+                       torch.optim.Adam).  A caller may pass `f(actor_critic, ppo_epoch=, mini_batch_size=, lr=, mirror_indices=, use_graph=)`
+                       returning an object with PPO's `update` / `set_lr` contract (the out-of-scope fused learner under
+                       extras/fused_learner does; nothing in this package provides one)
     use_graph ("auto": on a GPU with a single rank): rollout and minibatch step replay as hipGraphs.  Episode returns go
     through a device ring of the last num_envs episodes in both modes (EpisodeRing = the reference's deque).
     Under torch.distributed (one rank per GPU) every rank passes its LOCAL envs: gradients and the advantage statistics
@@ -529,22 +552,9 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
         torch.manual_seed(seed + 7919 * rank)            # decorrelate exploration noise / minibatch order across ranks
     mirror = envs.get_mirror_indices() if use_mirror and hasattr(envs, "get_mirror_indices") else None
     n = envs.num_envs
-    fused_ok = dev.type == "cuda" and mini_batch_size % 32 == 0 and (num_steps * n) % mini_batch_size == 0
-    if learner == "fused" and not fused_ok:
-        raise ValueError("learner='fused' needs a GPU and a minibatch (multiple of 32) dividing the rank's rollout")
-    if learner not in ("torch", "fused", "auto"):
-        raise ValueError("learner must be 'torch', 'fused' or 'auto', got %r" % (learner,))
-    agent = None
-    if learner == "fused" or (learner == "auto" and fused_ok):
-        from .fused_ppo import FusedLearnerError, FusedPPO
-        try:
-            agent = FusedPPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror,
-                             use_graph=bool(use_graph))
-        except FusedLearnerError as exc:
-            if learner == "fused":                         # asked for explicitly: fail loudly
-                raise
-            print("steppingstone_amd.ppo.train: fused learner unavailable (%s); using the torch learner" % exc)
-    if agent is None:
+    if agent_factory is not None:
+        agent = agent_factory(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=bool(use_graph))
+    else:
         agent = PPO(ac, ppo_epoch=ppo_epoch, mini_batch_size=mini_batch_size, lr=lr, mirror_indices=mirror, use_graph=graph_update)
     roll = Rollouts(num_steps, n, dev)
     ring = EpisodeRing(n, dev)

@@ -41,9 +41,6 @@ def main():
     ap.add_argument("--test-interval", type=int, default=10, help="deterministic test episodes every K updates (reference: 1; 0 = off)")
     ap.add_argument("--mirror", action="store_true")                # use_mirror
     ap.add_argument("--no-graph", action="store_true", help="run rollout and minibatch steps eagerly (no hipGraph)")
-    ap.add_argument("--learner", default="torch", choices=["torch", "fused", "auto"],
-                    help="minibatch step: autograd + torch Adam on PyTorch-ROCm (default, BASELINE configs[4]) or the hand-written "
-                         "MFMA kernels (fused, opt-in)")
     ap.add_argument("--log-dir", default="", help="progress.csv with the reference's columns (common/csv_utils.py)")
     ap.add_argument("--save-dir", default="", help="{env}_latest.pt / _best.pt / _{frames}.pt (train.py:523-562)")
     ap.add_argument("--save-every", type=float, default=1e7)        # train.py:43
@@ -84,7 +81,7 @@ def main():
                          use_graph=False if args.no_graph else "auto", sampling=sampling, eval_envs=eval_envs,
                          curriculum_threshold=args.curriculum_threshold, test_envs=test_envs,
                          test_interval=args.test_interval, logger=logger, save_dir=args.save_dir,
-                         save_every=args.save_every, env_name=env_name, learner=args.learner)
+                         save_every=args.save_every, env_name=env_name)
     if args.save and rank == 0:
         torch.save(ac.state_dict(), args.save)
     if world > 1:

@@ -86,26 +86,3 @@ def test_header_is_plain_c_and_usable_without_python(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert "create rc -3" in out.stdout and "no CPU fallback" in out.stdout
-
-
-def test_learner_header_symbols_are_exported():
-    """include/steppingstone_learner.h (fused PPO minibatch step): every declared entry point is exported, the flat
-    parameter layout of the Python side equals the library's, and creation fails loudly without a GPU."""
-    import torch
-    from steppingstone_amd import fused_ppo
-    if not os.path.exists(fused_ppo.LIB_PATH):
-        pytest.skip("opt-in fused learner not built (SS_BUILD_LEARNER=1 python -m steppingstone_amd.build)")
-    src = open(os.path.join(ROOT, "include", "steppingstone_learner.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = sorted(set(re.findall(r"\b(ssl_[a-z_0-9]+)\s*\(", src)))
-    lib = fused_ppo.load()
-    assert set(names) == set(fused_ppo.SYMBOLS)
-    for n in names:
-        assert hasattr(lib, n), n
-    for e in (1, 2, 4):
-        assert fused_ppo.layout(e)[1] == lib.ssl_num_params(e)
-    assert lib.ssl_num_params(0) == -1 and lib.ssl_num_params(5) == -1
-    if not torch.cuda.is_available():
-        h = C.c_void_p()
-        assert lib.ssl_create(C.byref(h), 0, 1, 1024) == -3 and not h.value
-        assert b"no CPU path" in lib.ssl_last_error()

@@ -80,7 +80,7 @@ def _train_worker(rank, port, ret):
     from steppingstone_amd import ppo
     from steppingstone_amd.envs import SteppingStoneVecEnv
     envs = SteppingStoneVecEnv("Walker3DStepperEnv-v0", 256, seed=8, device="cuda:0", return_numpy=False, env_id_offset=rank * 256)
-    ac, hist = ppo.train(envs, num_updates=3, num_steps=8, ppo_epoch=2, mini_batch_size=512, log=None, learner="torch")
+    ac, hist = ppo.train(envs, num_updates=3, num_steps=8, ppo_epoch=2, mini_batch_size=512, log=None)
     ret[rank] = (torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).cpu().numpy(),
                  [(h["value_loss"], h["action_loss"]) for h in hist], hist[-1]["total_num_steps"])
     dist.barrier()

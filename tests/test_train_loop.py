@@ -105,6 +105,12 @@ def test_training_loop_with_threshold_sampler_logs_and_checkpoints(tmp_path):
     with pytest.raises(ValueError, match="policy convention"):
         ppo.load_checkpoint(str(tmp_path / "ckpt" / "abi3.pt"))
     ppo.load_checkpoint(str(tmp_path / "ckpt" / "abi3.pt"), allow_convention_mismatch=True)
+    # round 6: the env's numbers travel too (warning-level): a file from an env with other robot tables loads, loudly
+    assert ck["env_fingerprint"] == ppo.env_fingerprint()
+    other = dict(ck, env_fingerprint="0" * 64)
+    torch.save(other, str(tmp_path / "ckpt" / "other_robot.pt"))
+    with pytest.warns(RuntimeWarning, match="other robot / terrain numbers"):
+        ppo.load_checkpoint(str(tmp_path / "ckpt" / "other_robot.pt"))
 
 
 def test_adaptive_sampler_and_specialist_switches():

@@ -48,7 +48,15 @@ def test_tensor_mode_and_hooks():
     env.update_sample_prob(per_env / per_env.sum(axis=(1, 2), keepdims=True))
     with pytest.raises(ValueError):
         env.update_sample_prob(np.zeros((4, 11, 11)))
-    env.set_mirror(True)
+    import warnings
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    SteppingStoneVecEnv._warned_set_mirror = False
+    with pytest.warns(RuntimeWarning, match="phase mirroring"):       # use_phase_mirror is unsupported: said once, not silently accepted
+        env.set_mirror(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        env.set_mirror(True)                                           # ... once per process
+        env.set_mirror(False)
     env.set_robot_params({"power": 0.8})
     env.set_env_params({"curriculum": 1})
     with pytest.raises(KeyError):

@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 MODELS = "/root/reference/playground/models/"
 POLICY = {"walker3d": "mocca_envs:Walker3DStepperEnv-v0_latest.pt", "mike": "mocca_envs:MikeStepperEnv-v0_latest.pt"}
+# held-out sibling (never fitted; round 6 validates on it): another Walker3D actor of the reference
+POLICY_ALT = {"walker3d:base": "mocca_envs:Walker3DStepperEnv-v0_base.pt"}
 
 # ------------------------------------------------------------------------------------------------ the search space
 # (name, kind of coordinate, initial std in search units, lo, hi).  "log": multiplier exp(x) on the default; "add": default + x.
@@ -67,6 +69,47 @@ def space():
     return S
 
 
+def space_plausible():
+    """ROUND 6: the same coordinates inside STATED PLAUSIBILITY BOUNDS, so that the result is a robot and
+    not only a black-box fit -- mass multipliers and torque limits within x 0.5-2 of the rounds-1-4 numbers, segment lengths within
+    x 0.7-1.4, friction <= 1.2, joint ranges within +-30 degrees, bounded passive damping / stiffness (the spine at most 10 x the
+    global scale), the limit spring within 10-200 N m / rad per N m, the sole 4-10 cm below the ankle AND the foot box derived from it
+    (`foot_on_sole`), the nominal pose strictly inside the ranges (projection in overrides_of: every q0 at least 4 degrees inside, so
+    that the reset noise of +-2.9 degrees is never clipped; hip x has its own nominal angle for that), and the stones' contact radius
+    at most half the smallest stone spacing (0.325 m: neighbouring discs never overlap)."""
+    from steppingstone_amd import model
+    L2 = float(np.log(2.0))
+    S = []
+    for g in model.MASS_GROUPS:
+        S.append(LOGM("mass_mult." + g, 0.15, -L2, L2))
+    for k in ("thigh", "shin", "upper_arm", "lower_arm", "hip_y", "torso_w"):
+        S.append(LOGM(k, 0.06, -0.35, 0.35))
+    S += [ADD("hip_z", 0.02, -0.10, 0.10), ADD("spine_r2", 0.02, -0.08, 0.08), ADD("spine_r0.z", 0.02, -0.08, 0.08),
+          ADD("knee_gap", 0.01, -0.03, 0.04), ADD("ankle_gap", 0.01, -0.03, 0.05),
+          ADD("sole.front", 0.02, -0.06, 0.08), ADD("sole.back", 0.02, -0.06, 0.04), ADD("sole.half_width", 0.01, -0.02, 0.04),
+          ADD("sole.z", 0.01, -0.025, 0.035)]
+    for t in model.JOINT_TYPES:
+        S.append(LOGM("torque." + t, 0.15, -L2, L2))
+    S += [LOGM("abdomen.damping", 0.4, -2.0, 2.3), LOGM("abdomen.stiffness", 0.4, -2.0, 2.3)]
+    S += [LOGM("scale.damping", 0.4, -2.5, 1.0), LOGM("scale.stiffness", 0.4, -2.5, 1.5), LOGM("scale.armature", 0.4, -1.5, 1.5),
+          LOGM("k_lim_per_torque", 0.3, -1.6, 1.4), LOGM("d_lim_per_k", 0.3, -1.5, 1.5)]
+    for t in model.JOINT_TYPES:
+        S += [ADD("range_lo." + t, 5.0, -30.0, 30.0), ADD("range_hi." + t, 5.0, -30.0, 30.0)]
+    S += [ADD("q0_deg.hip_x", 2.0, -15.0, 10.0), ADD("q0_deg.hip_y", 4.0, -35.0, 20.0), ADD("q0_deg.knee", 5.0, -20.0, 50.0),
+          ADD("q0_deg.ankle", 4.0, -25.0, 25.0), ADD("q0_deg.elbow", 8.0, -60.0, 60.0)]
+    S.append(LOGM("friction", 0.12, -0.6, float(np.log(1.2 / 0.9))))
+    # the stepping surface: a PLANK, footprint 2 a x 2 b aligned with the stone's heading (SURVEY 9 recollects plank-shaped step bodies;
+    # the round-6 scan shows plank 0.30 x 0.40 = disc 0.45 for the shipped policy).  a = 0.30 m is fixed: the longest plank that cannot
+    # overlap its neighbour at the smallest stone spacing of 0.65 m; the half-width b is searched
+    S.append(ADD("env.plank_b", 0.04, -0.10, 0.20))
+    return S
+
+
+PLANK_A = 0.30
+PLAUSIBLE = False        # --plausible: the bounded space above + the projections in overrides_of
+Q0_MARGIN_DEG = 4.0
+
+
 def overrides_of(kind, x, S):
     """search vector -> the `overrides` dict of steppingstone_amd.model.build"""
     from steppingstone_amd import model
@@ -78,6 +121,8 @@ def overrides_of(kind, x, S):
     for (name, how, _, lo, hi), v in zip(S, np.clip(x, [s[3] for s in S], [s[4] for s in S])):
         if name == "env.stone_radius":
             ov["env.stone_radius"] = 0.25 + float(v)
+        elif name == "env.plank_b":
+            ov["env.plank_b"] = float(v)
         elif name.startswith("abdomen."):
             spine[name.split(".")[1]] = float(np.exp(v))
         elif name.startswith("scale."):
@@ -112,12 +157,33 @@ def overrides_of(kind, x, S):
             mid = 0.5 * (lo + hi)
             lo, hi = mid - 5.0, mid + 5.0
         ov["range." + t] = (lo, hi)
+    if "env.plank_b" in ov:
+        ov["env.plank"] = (PLANK_A, 0.40 + ov.pop("env.plank_b"))
     if FIXED_STONE_RADIUS:
         ov["env.stone_radius"] = FIXED_STONE_RADIUS     # an ENV constant: one value for both robots in the final stages
     sole[2] = max(sole[2], 0.015)
     sole[0] = max(sole[0], sole[1] + 0.04)
     ov["sole"] = tuple(sole)
     ov["spine_r0"] = tuple(r0)
+    if PLAUSIBLE:
+        ov["foot_on_sole"] = True
+        # the nominal pose strictly inside the ranges (right side's +axis convention, like DEFAULTS["range"]); joints without a
+        # q0 coordinate rest at 0 and their range is widened to contain it
+        q0 = dict(D["q0_deg"])
+        for k in list(ov):
+            if k.startswith("q0_deg."):
+                q0[k.split(".")[1]] = ov[k]
+        for t in model.JOINT_TYPES:
+            lo, hi = ov["range." + t]
+            if t in q0:
+                q = min(max(q0[t], lo + Q0_MARGIN_DEG), hi - Q0_MARGIN_DEG)
+                ov["q0_deg." + t] = q
+            else:
+                lo, hi = min(lo, -Q0_MARGIN_DEG), max(hi, Q0_MARGIN_DEG)
+                if t in ("abdomen_z", "abdomen_x"):
+                    half = max(-lo, hi)
+                    lo, hi = -half, half
+                ov["range." + t] = (lo, hi)
     return ov
 
 
@@ -154,20 +220,38 @@ def _init_worker(kind):
     _W["lib"].sso_debug_set_model.argtypes = [C.c_int, C.c_void_p]
     assert _W["lib"].sso_model_size() == C.sizeof(SsoModel), "sso_model layout changed"
     _W["actor"] = load_reference_checkpoint(MODELS + POLICY[kind]).actor
+    _W["actors"] = {"latest": _W["actor"]}
+    for key, f in POLICY_ALT.items():
+        if key.startswith(kind + ":"):
+            _W["actors"][key.split(":")[1]] = load_reference_checkpoint(MODELS + f).actor
     _W["kind"] = kind
     _W["torch"] = torch
 
 
-def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
-    """deterministic shipped actor in the oracle with model overrides `ov`: first episode of each of n envs"""
+def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False, policy="latest", env=None, use_identified=False):
+    """deterministic shipped actor in the oracle with model overrides `ov`: first episode of each of n envs.  `env`: terrain / contact
+    study knobs of the ORACLE only (plank=(a, b), dr=(lo, span), target_carried=0/1, stone_radius)."""
     from steppingstone_amd import model
-    ol, lib, torch, actor = _W["ol"], _W["lib"], _W["torch"], _W["actor"]
+    ol, lib, torch = _W["ol"], _W["lib"], _W["torch"]
+    actor = _W["actors"][policy]
     ov = dict(ov)
-    stone_r = ov.pop("env.stone_radius", None)
+    env = dict(env or {})
+    stone_r = env.get("stone_radius", ov.pop("env.stone_radius", None))
+    ov.pop("env.stone_radius", None)
+    plank = ov.pop("env.plank", None)
+    if plank is not None and "plank" not in env and "stone_radius" not in env:
+        env["plank"] = plank
     lib.sso_debug_set_stone_radius.argtypes = [C.c_double]
+    lib.sso_debug_set_plank.argtypes = [C.c_double, C.c_double]
+    lib.sso_debug_set_dr.argtypes = [C.c_double, C.c_double]
     lib.sso_debug_set_stone_radius(float(stone_r) if stone_r is not None else SPEC_STONE_RADIUS)
+    lib.sso_debug_set_plank(*[float(v) for v in env.get("plank", (0.0, 0.0))])
+    lib.sso_debug_set_dr(*[float(v) for v in env.get("dr", (0.65, 0.6))])
+    lib.sso_debug_set_target_rule(int(env.get("target_carried", TARGET_CARRIED)))
+    lib.sso_debug_set_target_radius.argtypes = [C.c_double]
+    lib.sso_debug_set_target_radius(float(env.get("target_radius", 0.0)))
     try:
-        m = model.build(kind, ov, use_identified=False)        # the search is relative to the rounds-1-4 prior
+        m = model.build(kind, ov, use_identified=use_identified)        # the search is relative to the rounds-1-4 prior
     except Exception:
         return (-1.0, {}) if detail else -1.0
     sm = pack_model(m)
@@ -204,8 +288,10 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False):
     return score
 
 
+TARGET_CARRIED = 0       # --target-carried: on-target only through a corner that stone n carries (the round-6 rule)
 FIXED_STONE_RADIUS = 0.0 # --stone-radius in a search: the coordinate is frozen at this value
 SPEC_STONE_RADIUS = 0.25 # what a model without an "env.stone_radius" override is evaluated with
+STEPS = 500              # --steps: control steps per evaluation episode
 CURRICULA = [0]          # --curricula: terrains averaged in the score (0 = flat, 5 = the full yaw x pitch grid)
 PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of each coordinate's std): pulls numbers the score does not need back
 
@@ -213,7 +299,8 @@ PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of
 def _eval(args):
     x, S = args
     ov = overrides_of(_W["kind"], x, S)
-    sc = float(np.mean([rollout(_W["kind"], ov, n=64 if len(CURRICULA) == 1 else 48, seed=9 + 100 * c, curriculum=c) for c in CURRICULA]))
+    sc = float(np.mean([rollout(_W["kind"], ov, n=64 if len(CURRICULA) == 1 else (48 if len(CURRICULA) < 4 else 40), steps=STEPS, seed=9 + 100 * c,
+                                curriculum=c) for c in CURRICULA]))
     if PRIOR:
         std = np.array([s_[2] for s_ in S])
         sc -= PRIOR * float(np.mean((np.asarray(x) / std) ** 2))
@@ -266,6 +353,63 @@ class CMA:
             self.D, self.B = np.sqrt(np.maximum(d, 1e-20)), B
 
 
+def _scan_one(job):
+    kind, ov, use_id, policy, cur, env, seed = job
+    _, d = rollout(kind, ov, n=96, steps=800, seed=seed, curriculum=cur, detail=True, policy=policy, env=env, use_identified=use_id)
+    return d
+
+
+def scan(args, S, names, std):
+    """The terrain / contact study: how far the shipped actors get when ONE thing about the stones changes."""
+    if args.scan == "spec":
+        ov, use_id = {}, True
+    else:
+        best = json.load(open(args.scan))
+        x = np.array([best["x"].get(n, 0.0) for n in names])
+        ov, use_id = overrides_of(args.kind, x * std, S), False
+    r_spec = ov.get("env.stone_radius", None)
+    if r_spec is None:
+        from steppingstone_amd import model
+        r_spec = model.env_constants()["stone_contact_radius"]
+    plank = ov.get("env.plank")
+    base_env = {"plank": plank} if plank else {"stone_radius": r_spec}
+    variants = [("as specified (%s)" % ("plank %.2f x %.2f" % tuple(plank) if plank else "disc R_c = %.3f" % r_spec), {}),
+                ("INFINITE PLANE for contact, target logic on a 0.45 disc", {"stone_radius": 1000.0, "target_radius": 0.45}),
+                ("disc R_c = 0.25", {"stone_radius": 0.25}), ("disc R_c = 0.30", {"stone_radius": 0.30}), ("disc R_c = 0.325", {"stone_radius": 0.325}),
+                ("disc R_c = 0.40", {"stone_radius": 0.40}), ("disc R_c = 0.45", {"stone_radius": 0.45}), ("disc R_c = 0.55", {"stone_radius": 0.55}),
+                ("plank 0.25 x 0.40 (half length x half width)", {"plank": (0.25, 0.40)}), ("plank 0.30 x 0.40", {"plank": (0.30, 0.40)}),
+                ("plank 0.30 x 0.60", {"plank": (0.30, 0.60)}), ("plank 0.40 x 0.30", {"plank": (0.40, 0.30)}),
+                ("on-target rule: other (carried = %d)" % (1 - TARGET_CARRIED), {"target_carried": 1 - TARGET_CARRIED}),
+                ("stone spacing 0.65 + u 0.35 c/5 (max 1.00 m)", {"dr": (0.65, 0.35)}), ("stone spacing 0.55 + u 0.6 c/5", {"dr": (0.55, 0.6)}),
+                ("stone spacing 0.75 + u 0.5 c/5", {"dr": (0.75, 0.5)})]
+    policies = ["latest"] + [k.split(":")[1] for k in POLICY_ALT if k.startswith(args.kind + ":")]
+    jobs, keys = [], []
+    for label, env in variants:
+        for pol in policies:
+            for cur in CURRICULA:
+                if cur == 0 and "dr" in env:
+                    continue
+                if "INFINITE" in label and cur != 0:
+                    continue
+                e = dict(env) if ("stone_radius" in env or "plank" in env) else dict(base_env, **env)
+                jobs.append((args.kind, ov, use_id, pol, cur, e, 1234))
+                keys.append((label, pol, cur))
+    pool = mp.get_context("fork").Pool(args.workers, initializer=_init_worker, initargs=(args.kind,))
+    res = pool.map(_scan_one, jobs, chunksize=1)
+    pool.close()
+    print("# %s, deterministic shipped actors, fp32 CPU oracle, 96 envs x 800 steps, seed 1234 (never used by a search); model: %s; "
+          "on-target rule: carried = %d" % (args.kind, args.scan, TARGET_CARRIED))
+    print("# mean stones beyond the start / median / share >= 5 stones / mean episode steps")
+    for label, _ in variants:
+        for pol in policies:
+            cells = []
+            for cur in CURRICULA:
+                if (label, pol, cur) in keys:
+                    d = res[keys.index((label, pol, cur))]
+                    cells.append("c%d: %5.2f / %4.1f / %3.0f %% / %3.0f" % (cur, d["mean_stones"], d["median_stones"], 100 * d["frac_5_stones"], d["mean_steps"]))
+            print("%-52s %-7s %s" % (label, pol, "   ".join(cells)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="walker3d")
@@ -283,15 +427,24 @@ def main():
     ap.add_argument("--curricula", default="0", help="comma-separated curriculum levels averaged in the score")
     ap.add_argument("--prior", type=float, default=0.0, help="L2 pull towards the specification's defaults (per mean squared std)")
     ap.add_argument("--sigma0", type=float, default=0.0)
+    ap.add_argument("--plausible", action="store_true", help="round 6: the bounded space (space_plausible) and its projections")
+    ap.add_argument("--target-carried", type=int, default=0, help="1: the round-6 on-target rule (a corner CARRIED by stone n)")
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--scan", default="", help="terrain / contact study of a *_best.json ('spec' = the compiled-in specification): "
+                    "contact radius, infinite plane, plank shapes, stone spacing, on-target rule x curricula x policies")
     args = ap.parse_args()
-    global CURRICULA, PRIOR, FIXED_STONE_RADIUS
+    global CURRICULA, PRIOR, FIXED_STONE_RADIUS, PLAUSIBLE, TARGET_CARRIED, STEPS
+    PLAUSIBLE, TARGET_CARRIED, STEPS = args.plausible, args.target_carried, args.steps
     if args.stone_radius and not (args.emit or args.evaluate or args.ablate):
         FIXED_STONE_RADIUS = args.stone_radius
     CURRICULA = [int(c) for c in args.curricula.split(",")]
     PRIOR = args.prior
-    S = space()
+    S = space_plausible() if PLAUSIBLE else space()
     names = [s[0] for s in S]
     std = np.array([s[2] for s in S])
+    if args.scan:
+        scan(args, S, names, std)
+        return
     if args.evaluate:
         _init_worker(args.kind)
         best = json.load(open(args.evaluate))
