@@ -509,7 +509,7 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
           gamma=0.99, gae_lambda=0.95, ppo_epoch=10, mini_batch_size=1024, log=print, use_graph="auto",
           sampling="none", eval_envs=None, curriculum_threshold=0.85, uniform_every=500000,
           test_envs=None, test_interval=1, logger=None, save_dir="", save_every=1e7, env_name="env",
-          use_specialist=False, agent_factory=None):
+          use_specialist=False, agent_factory=None, on_rollout=None):
     """The training loop of playground/train.py:211-578 on device tensors.  Returns (actor_critic, per-update stats).
 
       use_curriculum   fixed-order curriculum: level += 1 while mean(recent episode returns) > 1000 (train.py:115-118,503-506)
@@ -523,6 +523,8 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
       logger           ConsoleCSVLogger-compatible object (steppingstone_amd.csv_logger): log_epoch(dict) per update
       save_dir         `{env}_latest.pt` every update, `{env}_{frames}.pt` every save_every frames, `{env}_best.pt` on a new
                        best mean return (train.py:523-562)
+      on_rollout       optional `f(update_index, rollouts)` called after every collection, before the returns are computed (tests: the
+                       rollout a rank trained on is compared with a single-process env replaying its actions)
       agent_factory    None: the learner is steppingstone_amd.ppo.PPO (BASELINE configs[4]: "actor/critic on PyTorch-ROCm": autograd +
                        torch.optim.Adam).  A caller may pass `f(actor_critic, ppo_epoch=, mini_batch_size=, lr=, mirror_indices=, use_graph=)`
                        returning an object with PPO's `update` / `set_lr` contract (the out-of-scope fused learner under
@@ -606,6 +608,8 @@ def train(envs, num_updates, num_steps=32, num_ensembles=1, seed=8, use_curricul
             collector()
         else:
             collect(envs, ac, roll, num_steps, ring=ring)
+        if on_rollout is not None:
+            on_rollout(j, roll)
         if sampling == "threshold":                       # train.py:460-469
             uniform_sampling = (uniform_counter % uniform_every == 0)
             uniform_counter = 0 if uniform_sampling else uniform_counter

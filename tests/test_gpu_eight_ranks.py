@@ -96,5 +96,6 @@ def test_bench_gpus_8_runs_the_configs3_workload_end_to_end_on_one_gpu():
     assert d["config"]["workload"].startswith("Walker3DStepperEnv-v0") and "test_transport" in d["config"]
     assert d["gather_verified"] is True and d["rccl_ranks"] == 8 and d["transport"] == "gloo"
     assert d["value"] > 0 and d["no_gather"]["value"] > 0 and d["per_step_gather"]["value"] > 0
+    assert d["value_per_step_exchange"] == d["per_step_gather"]["value"] and d["rccl"]["ranks"] == 8
     assert len(d.get("pci_bus_ids", d["config"].get("pci_bus_ids", [None] * 8))) == 8
     print(json.dumps({k: d[k] for k in ("value", "ms_per_step", "gather_verified", "transport")}))
