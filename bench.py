@@ -35,14 +35,15 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 ENV_ID = "Walker3DStepperEnv-v0"
 # ALGORITHMIC HBM bytes per env-step with this repository's state layout:
-#   one launch per step: read 84 f32 state / stone-cache fields + 4 i32 = 352 B; write 60 f32 + 5 i32 state = 260 B,
-#                        obs 240 B, rew 4 B, done 1 B, info 24 B = 529 B                                     -> 881 B
-#   K steps per launch:  the 352 B are read once per launch, the 529 B written every step; the epilogue's re-read of
-#                        the 13 bookkeeping words + stone cache is served by L2                 -> 529 + 352/K B
-# (rounds 1-2: 348 + 521 = 869 B, before the second word of the episode return: ss_info.ep_ret_lo, fstate row 83.)
-# roofline.achieved is computed from the 881 B per-unit figure for both launch shapes; the smaller figure of
+#   one launch per step: read 90 f32 state / stone-cache fields + 4 i32 = 376 B; write 60 f32 + 5 i32 state = 260 B,
+#                        obs 240 B, rew 4 B, done 1 B, info 24 B = 529 B                                     -> 905 B
+#   K steps per launch:  the 376 B are read once per launch, the 529 B written every step; the epilogue's re-read of
+#                        the 13 bookkeeping words + stone cache is served by L2                 -> 529 + 376/K B
+# (rounds 1-2: 348 + 521 = 869 B, before the second word of the episode return: ss_info.ep_ret_lo; rounds 3-5: 352 + 529 = 881 B,
+#  before the six heading words of the three active stones (the plank footprint, PHYSICS.md 3.3): fstate rows 83..88.)
+# roofline.achieved is computed from the 905 B per-unit figure for both launch shapes; the smaller figure of
 # the K-step kernel and the PMC-measured traffic are reported beside it.
-ALGO_READ_B, ALGO_WRITE_B = 352, 529
+ALGO_READ_B, ALGO_WRITE_B = 376, 529
 HBM_PEAK_GBS = 8000.0
 VALU_FP32_PEAK_TFLOPS = 157.3          # packed-f32 vector peak (MI355X_MICROARCH.md): 256 CUs x 2.4 GHz x 256 flop/clk
 
@@ -509,12 +510,12 @@ def main():
         total_envs = n_local * world
         value = total_envs * K / elapsed
         steps_in_launch = spl if multi_step else (32 if chunked else 1)
-        # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (881 B per env-step: the state
-        # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 352 B
+        # roofline.achieved uses SURVEY 8(d)'s per-unit figure recomputed for this layout (905 B per env-step: the state
+        # round trip a step() implies) x the env-steps one launch processes.  The K-step kernel really moves less (the 376 B
         # of state are read once per launch): that figure is reported next to it, as is the PMC-measured traffic.
-        #  `achieved` / `frac` are for the launch shape that is TIMED: a K-step launch reads the 352 B of state
-        # once per launch, so its own algorithmic need is 529 + 352 / K B per env-step; 881 B (the state round trip every step()
-        # implies) applies to one launch per step.  The 881-B figure stays beside it as a first-class field.
+        #  `achieved` / `frac` are for the launch shape that is TIMED: a K-step launch reads the 376 B of state
+        # once per launch, so its own algorithmic need is 529 + 376 / K B per env-step; 905 B (the state round trip every step()
+        # implies) applies to one launch per step.  The 905-B figure stays beside it as a first-class field.
         algo_roundtrip = float(ALGO_WRITE_B + ALGO_READ_B)
         algo_per_env_step = ALGO_WRITE_B + ALGO_READ_B / float(steps_in_launch)
         launch_ms = kernel_ms_per_step * steps_in_launch
@@ -562,7 +563,7 @@ def main():
                          "algorithmic_bytes_is": ("%d B written + %d B of state read once per %d-step launch" % (ALGO_WRITE_B, ALGO_READ_B, steps_in_launch)),
                          "state_roundtrip_every_step": {"algorithmic_bytes_per_env_step": algo_roundtrip, "achieved": achieved_roundtrip,
                                                         "frac": achieved_roundtrip / HBM_PEAK_GBS,
-                                                        "note": "the same kernel time priced at SURVEY 8(d)'s 881 B per env-step (state read AND "
+                                                        "note": "the same kernel time priced at SURVEY 8(d)'s 905 B per env-step (state read AND "
                                                                 "written every step): what a one-launch-per-step caller's traffic would be"},
                          "note": pmc_note(pmc), "note_source": pmc_src},
         }

@@ -46,7 +46,6 @@ typedef SSO_REAL real;
 #define H_SUB ((real)(1.0 / 240.0))
 #define DT_CTRL ((real)(1.0 / 60.0))
 #define GRAV ((real)9.8)
-#define STONE_R ((real)SSO_STONE_CONTACT_RADIUS)   /* contact radius of a stone (ss_model_tables.h; PHYSICS.md 3.3) */
 #define STEP_RADIUS ((real)0.25)                    /* the reference's step_radius: scale of the step bonus (PHYSICS.md 4.5) */
 #define PGS_ITERS 5   /* PHYSICS.md 3.4 (Bullet's numSolverIterations = 5); rounds 1-4: 8 */
 #define PGS_WARM 1    /* warm start from the previous substep of the same control step; rounds 1-4: none */
@@ -400,24 +399,22 @@ static void stone_normal(const real* st, real nrm[3]) {
   nrm[0] = Rs.m[0][2]; nrm[1] = Rs.m[1][2]; nrm[2] = Rs.m[2][2];
 }
 
-/* contact radius of a stone (tools/sysid_policy.py's terrain study ONLY; the specification's value is STONE_R) */
-static real g_stone_r = STONE_R;
+/* The stepping surface (PHYSICS.md 3.3, round 6): a PLANK whose footprint seen from above is 2 a x 2 b, aligned with the stone's heading
+ * phi: with l the in-plane offset of the corner from the stone's centre, u = l_x cos(phi) + l_y sin(phi) along the heading and
+ * v = l_y cos(phi) - l_x sin(phi) across it; inside when |u| < a and |v| < b.  a, b: SSO_PLANK_HALF_LENGTH / _WIDTH of the tables.
+ * Study knobs (tools/sysid_policy.py ONLY; never the specification): another plank, a DISC of radius r instead (rounds 1-5: 0.25 m, then
+ * 0.45 m), another stone spacing law, the rounds-1-5 on-target rule, an extra target radius (infinite-plane control). */
+static real g_plank_a = SSO_PLANK_HALF_LENGTH, g_plank_b = SSO_PLANK_HALF_WIDTH;
+void sso_debug_set_plank(double a, double b) { g_plank_a = a > 0 ? (real)a : SSO_PLANK_HALF_LENGTH; g_plank_b = a > 0 ? (real)b : SSO_PLANK_HALF_WIDTH; }
+static real g_stone_r = 0;      /* > 0: disc study mode */
 void sso_debug_set_stone_radius(double r) { g_stone_r = (real)r; }
-/* contact SHAPE study (tools/sysid_policy.py --scan ONLY; never the specification): a > 0 replaces the disc by a rectangle in the
- * stone's plane, half-length a along the stone's own x axis (R_s e_x, the direction of travel) and half-width b across it */
-static real g_plank_a = 0, g_plank_b = 0;
-void sso_debug_set_plank(double a, double b) { g_plank_a = (real)a; g_plank_b = (real)b; }
-/* stone spacing study (same tool, same status): dr = lo + u * span * curriculum / 5; the specification is 0.65 + u * 0.6 * c / 5 */
 static real g_dr_lo = (real)0.65, g_dr_span = (real)0.6;
 void sso_debug_set_dr(double lo, double span) { g_dr_lo = (real)lo; g_dr_span = (real)span; }
-/* on-target rule study: 1 = a foot is on the target only through a corner that stone n CARRIES (wins), 0 = the specification's rule */
-static int g_target_carried = 0;
-static real g_target_r = 0;     /* > 0: on-target additionally needs the corner within this radius of stone n's axis (infinite-plane control) */
+static int g_target_carried = 1;    /* 1 (specification): a foot is on the target through a corner that stone n CARRIES; 0: rounds 1-5 */
+static real g_target_r = 0;     /* > 0, with the rounds-1-5 rule: the corner must also lie within this radius of stone n's axis */
 void sso_debug_set_target_rule(int carried_only) { g_target_carried = carried_only; }
 void sso_debug_set_target_radius(double r) { g_target_r = (real)r; }
 static int plank_inside(const real* st, const real* l, real* margin) {
-  /* footprint seen from above: the in-plane offset l of the corner from the stone's centre, its horizontal components along / across the
-   * stone's heading phi */
   real c = r_cos(st[3]), sn = r_sin(st[3]);
   real u = l[0] * c + l[1] * sn, v = l[1] * c - l[0] * sn;
   real mu = g_plank_a - (u < 0 ? -u : u), mv = g_plank_b - (v < 0 ? -v : v);
@@ -447,14 +444,13 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         real d = dv[0] * nrm[0] + dv[1] * nrm[1] + dv[2] * nrm[2];
         real lx = dv[0] - d * nrm[0], ly = dv[1] - d * nrm[1], lz = dv[2] - d * nrm[2];
         real rho2 = lx * lx + ly * ly + lz * lz;
-        real g1 = -d, g2 = d + (real)0.10, g3 = g_dec ? g_stone_r - r_sqrt(rho2) : 0;
-        int inside = rho2 < g_stone_r * g_stone_r;
-        if (g_plank_a > 0) { real l3[3] = {lx, ly, lz}; inside = plank_inside(st, l3, &g3); }       /* shape study only */
+        real g1 = -d, g2 = d + (real)0.10, g3 = 0, l3[3] = {lx, ly, lz};
+        int inside = plank_inside(st, l3, &g3);
+        if (g_stone_r > 0) { inside = rho2 < g_stone_r * g_stone_r; g3 = g_stone_r - r_sqrt(rho2); }       /* disc study only */
         real gm = g1 < g2 ? g1 : g2;
         if (g3 < gm) gm = g3;
         int touch = decide(0, d < 0 && d > (real)-0.10 && inside, gm);
-        /* a foot is on the target when a corner touches stone n -- whichever stone carries that corner (with a contact radius
-         * beyond half the stone spacing the discs of neighbouring stones overlap, PHYSICS.md 3.3) */
+        /* rounds 1-5 (study only): on the target when a corner touches stone n, whichever stone carries that corner */
         if (touch && sl == 1 && !g_target_carried && (g_target_r <= 0 || rho2 < g_target_r * g_target_r)) fr->foot_on_target[f] = 1;
         /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
          * forced against d >= 0); an exact tie between COPLANAR stones goes to the lower slot and is not a decision -- either

@@ -29,7 +29,9 @@ namespace ss {
 constexpr float kH = 1.0f / 240.0f;
 constexpr float kDt = 1.0f / 60.0f;
 constexpr float kGrav = 9.8f;
-constexpr float kStoneR2 = kStoneContactRadius * kStoneContactRadius;   // ss_model_tables.hpp (PHYSICS.md 3.3)
+// the stepping surface of a stone (PHYSICS.md 3.3, round 6): a plank whose footprint, seen from above, is 2 kPlankA x 2 kPlankB, aligned
+// with the stone's heading (ss_model_tables.hpp: kStonePlankHalfLength / kStonePlankHalfWidth)
+constexpr float kPlankA = kStonePlankHalfLength, kPlankB = kStonePlankHalfWidth;
 // PHYSICS.md 3.4: 5 sweeps, warm-started from the previous substep of the same control step (Bullet's
 // numSolverIterations = 5 with warm starting; rounds 1-4 ran 8 cold sweeps -- DESIGN.md section 5.1 has the measured trade)
 #ifndef SS_PGS_ITERS
@@ -53,6 +55,8 @@ constexpr int kLdsSlots = 40;          // 40 float4 = 640 B per lane = 40,960 B 
 constexpr int kSlotsA = 20;            // region A: the contact operators C and T (72 floats per lane), output staging
 constexpr int kLdsC = 0;               // 6 columns x 3 float2: own-foot twist per unit impulse on the PARTNER's foot (T . mirror(G_partner))
 constexpr int kLdsT = 18;              // 6 columns x 3 float2: own-foot twist per unit pelvis twist
+constexpr int kLdsHead = 36;           // 3 float2: (cos, sin) of the heading of the active stones n-1, n, n+1 in this lane's world; items 36..38 of
+                                       // region A's 40 are beyond the operators (0..35) and beyond the output staging (the first 2240 floats)
 constexpr int kScalarBase = kSlotsA * kWave * 4;   // region B, in floats
 // helper-wavefront variant (small batches): a hand-off region behind the main wavefront's 40 slots -- the joint records
 // of the spine+leg chain (8 x 9 floats), the base Cholesky factor (21), and back: the six Lambda_own columns (36)
@@ -557,11 +561,14 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
   fr.on_target = 0;
   fr.sole[0] = fr.sole[1] = fr.sole[2] = 0.f;
   {
-    float sp[3][3], sn_[3][3];
+    float sp[3][3], sn_[3][3], hc[3], hs_[3];
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl)
+    for (int sl = 0; sl < 3; ++sl) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) { sp[sl][i] = L.s(S_STP + sl * 3 + i); sn_[sl][i] = L.s(S_STN + sl * 3 + i); }
+      const float2 hd = L.q2(kLdsHead + sl);
+      hc[sl] = hd.x; hs_[sl] = hd.y;
+    }
     static_for<0, 4>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value;
       constexpr float cx = Model::corners[k][0], cy = Model::corners[k][1], cz = Model::corners[k][2];
@@ -578,14 +585,15 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
         float dx = P[0] - sp[sl][0], dy = P[1] - sp[sl][1], dz = P[2] - sp[sl][2];
         float d = dx * sn_[sl][0] + dy * sn_[sl][1] + dz * sn_[sl][2];
         float lx = dx - d * sn_[sl][0], ly = dy - d * sn_[sl][1], lz = dz - d * sn_[sl][2];
-        float rho2 = lx * lx + ly * ly + lz * lz;
-        const bool touch = (d < 0.f) && (d > -0.10f) && (rho2 < kStoneR2);
-        // on the target = a corner within stone n's contact disc, whichever stone carries the corner (neighbouring discs overlap
-        // once the contact radius exceeds half the stone spacing, PHYSICS.md 3.3)
-        if (touch && sl == 1) fr.on_target = 1;
+        (void)lz;
+        // the plank's footprint seen from above: the horizontal components of the in-plane offset along / across the stone's heading
+        const float u = lx * hc[sl] + ly * hs_[sl], v = ly * hc[sl] - lx * hs_[sl];
+        const bool touch = (d < 0.f) && (d > -0.10f) && (fabsf(u) < kPlankA) && (fabsf(v) < kPlankB);
         if (touch && d < best) { best = d; slot = sl; }      // the deeper stone wins, an exact tie goes to the lower slot
       }
       o.pen[k] = -best;
+      // on the target = a corner CARRIED by stone n (round 6; rounds 1-5: within stone n's disc, whichever stone carried it)
+      if (slot == 1) fr.on_target = 1;
       if (slot >= 0) {
         active |= 1 << k;
         cslot |= slot << (2 * k);

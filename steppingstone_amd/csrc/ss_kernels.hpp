@@ -3,7 +3,7 @@
 //
 // HBM layout (structure of arrays, env index fastest so every field access of a wavefront is one coalesced
 // 256-byte transaction):
-//   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8 | ep_ret_lo
+//   fstate [NF][Npad] float : pos3 quat4 twist6 q21 qd21 pot z_init ep_ret nn_dr | 3 active stones x 8 | 3 x (cos, sin) of their headings | ep_ret_lo
 //   istate [NI][Npad] int   : next_step_index, target_reached_count, elapsed, rng_ctr, flags, prov_from
 //   terrain [20*6][Npad] float : terrain_info rows of the stones k < prov_from; the stones from prov_from on are the provisional
 //                                straight flat path (x = 0.75 k, everything else 0; PHYSICS.md 6) BY DEFINITION and their rows are
@@ -22,7 +22,7 @@
 namespace ss {
 
 enum { F_POS = 0, F_QUAT = 3, F_VEL = 7, F_Q = 13, F_QD = 34, F_POT = 55, F_ZINIT = 56, F_EPRET = 57, F_NNDR = 58,
-       F_STONE = 59, F_EPRET_LO = 59 + 24, NF = 59 + 24 + 1 };
+       F_STONE = 59, F_HEAD = 59 + 24, F_EPRET_LO = 59 + 30, NF = 59 + 30 + 1 };
 enum { I_N = 0, I_COUNT = 1, I_ELAPSED = 2, I_RNG = 3, I_FLAGS = 4, I_PROV = 5, NI = 6 };
 constexpr int kNumStones = 20;
 constexpr float kDeg = 0.017453292519943295f;
@@ -97,7 +97,7 @@ SSD int sample_cell(const Params& P, const Knobs& K, int e, float u) {
 
 // draw stone k from stone k-1 (terrain table), write it to the table; returns dr and the new stone's data
 SSD float draw_stone(const Params& P, const Knobs& K, int e, uint32_t& ctr, int k, float out_p[3], float out_n[3],
-                     float out_t[2], bool store = true) {
+                     float out_t[2], float out_h[2], bool store = true) {
   uint32_t r[4];
   env_block(P, e, ctr, r);
   int cell = sample_cell(P, K, e, u01(r[0]));
@@ -123,6 +123,7 @@ SSD float draw_stone(const Params& P, const Knobs& K, int e, uint32_t& ctr, int 
   out_p[1] = py + planar * sph;
   out_p[2] = pz + dr * sp;
   out_t[0] = xt; out_t[1] = yt;
+  out_h[0] = cph; out_h[1] = sph;
   stone_normal(phi, xt, yt, out_n);
   if (store) {
 #pragma unroll 1
@@ -255,8 +256,16 @@ SSD void store_cache(const Params& P, int e, const Cache& c) {
     F[(F_STONE + sl * 8 + 7) * np] = c.tilt[sl][1];
   }
 }
+// the active stones' headings (cos, sin of phi): what the plank footprint is aligned with (PHYSICS.md 3.3).  Their own 6 rows of fstate,
+// written on reset / advance / set_state only; inside a step they live in the lane's LDS (kLdsHead), never in the Cache registers
+SSD void store_headings(const Params& P, int e, const float (&h)[3][2]) {
+  float* F = P.fstate + e;
+  const size_t np = (size_t)P.npad;
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) { F[(F_HEAD + sl * 2) * np] = h[sl][0]; F[(F_HEAD + sl * 2 + 1) * np] = h[sl][1]; }
+}
 // rebuild the active-stone cache of env e from the terrain table (after set_state)
-SSD void cache_from_terrain(const Params& P, int e, int n, Cache& c) {
+SSD void cache_from_terrain(const Params& P, int e, int n, Cache& c, float (&hd)[3][2]) {
   const size_t np = (size_t)P.npad;
   const float* T = P.terrain + e;
   int idx[3] = {n - 1 < 0 ? 0 : n - 1, n, n + 1 > kNumStones - 1 ? kNumStones - 1 : n + 1};
@@ -268,6 +277,7 @@ SSD void cache_from_terrain(const Params& P, int e, int n, Cache& c) {
     float phi = T[(k * 6 + 3) * np], xt = T[(k * 6 + 4) * np], yt = T[(k * 6 + 5) * np];
     c.tilt[sl][0] = xt; c.tilt[sl][1] = yt;
     stone_normal(phi, xt, yt, c.nrm[sl]);
+    sincosf(phi, &hd[sl][1], &hd[sl][0]);
   }
 }
 
@@ -616,10 +626,14 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   {   // measured: merging these loads with the state loads below is slower (0.0867 vs 0.0857 ms/step)
     Cache c0;
     load_cache(P, e, c0);
+    float h0[3][2];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) { h0[sl][0] = F[(F_HEAD + sl * 2) * np]; h0[sl][1] = F[(F_HEAD + sl * 2 + 1) * np]; }
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
       L.s(S_STP + sl * 3 + 0) = c0.p[sl][0]; L.s(S_STP + sl * 3 + 1) = m * c0.p[sl][1]; L.s(S_STP + sl * 3 + 2) = c0.p[sl][2];
       L.s(S_STN + sl * 3 + 0) = c0.nrm[sl][0]; L.s(S_STN + sl * 3 + 1) = m * c0.nrm[sl][1]; L.s(S_STN + sl * 3 + 2) = c0.nrm[sl][2];
+      L.q2(kLdsHead + sl) = make_float2(h0[sl][0], m * h0[sl][1]);       // the heading in this lane's (y-mirrored) world
     }
   }
 
@@ -776,7 +790,12 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       }
       c.tilt[0][0] = c.tilt[1][0]; c.tilt[0][1] = c.tilt[1][1];
       c.tilt[1][0] = c.tilt[2][0]; c.tilt[1][1] = c.tilt[2][1];
-      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, K, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], valid && side == 0);
+      // the headings move with the stones: in the lane's LDS (its own world), slot 2 from the draw (at n = 19 it keeps the last stone's)
+      float hnew[2] = {L.q2(kLdsHead + 2).x, m * L.q2(kLdsHead + 2).y};
+      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, K, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], hnew, valid && side == 0);
+      L.q2(kLdsHead + 0) = L.q2(kLdsHead + 1);
+      L.q2(kLdsHead + 1) = L.q2(kLdsHead + 2);
+      L.q2(kLdsHead + 2) = make_float2(hnew[0], m * hnew[1]);
     }
   }
   // 6. progress
@@ -827,6 +846,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
       c.nrm[sl][0] = 0.f; c.nrm[sl][1] = 0.f; c.nrm[sl][2] = 1.f;
       c.tilt[sl][0] = 0.f; c.tilt[sl][1] = 0.f;
+      L.q2(kLdsHead + sl) = make_float2(1.f, 0.f);
     }
     pos[0] = 0.f; pos[1] = 0.f; pos[2] = Model::stand_height + 0.01f;
     quat[0] = 1.f; quat[1] = quat[2] = quat[3] = 0.f;
@@ -908,7 +928,12 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   }
   if (valid && side == 0) {            // the env-level scalars
     float* Fo = P.fstate + e;
-    if (advanced || do_reset) store_cache(P, e, c);
+    if (advanced || do_reset) {
+      store_cache(P, e, c);
+      const float hd[3][2] = {{L.q2(kLdsHead).x, L.q2(kLdsHead).y}, {L.q2(kLdsHead + 1).x, L.q2(kLdsHead + 1).y},
+                              {L.q2(kLdsHead + 2).x, L.q2(kLdsHead + 2).y}};      // side 0: its world is the true one
+      store_headings(P, e, hd);
+    }
     gst<!ROLLOUT>(&Fo[F_POT * np], pot_prev);
     gst<!ROLLOUT>(&Fo[F_ZINIT * np], z_init);
     gst<!ROLLOUT>(&Fo[F_EPRET * np], ep_ret);
@@ -1083,6 +1108,8 @@ __global__ __launch_bounds__(kWave) void reset_kernel(Params P, float* obs) {
   env_reset<Model>(P, e, s, c, ctr, pot, z_init, nn_dr);
   store_dyn(P, e, s);
   store_cache(P, e, c);
+  const float straight[3][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};      // the provisional path runs along +x
+  store_headings(P, e, straight);
   P.fstate[e + F_POT * np] = pot;
   P.fstate[e + F_ZINIT * np] = z_init;
   P.fstate[e + F_EPRET * np] = 0.f;
@@ -1254,8 +1281,10 @@ SSD void unpack_env(const Params& P, int e, const float* packed) {
   P.istate[e + I_PROV * np] = kNumStones;        // an injected terrain is stored in full
   P.fstate[e + (size_t)F_EPRET_LO * np] = o[185];
   Cache c;
-  cache_from_terrain(P, e, n, c);
+  float hd[3][2];
+  cache_from_terrain(P, e, n, c, hd);
   store_cache(P, e, c);
+  store_headings(P, e, hd);
 }
 #ifndef SS_HOST_HARNESS
 static __global__ void pack_state_kernel(Params P, float* packed) {

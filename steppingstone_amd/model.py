@@ -305,14 +305,16 @@ def identified(kind):
 
 
 def env_constants(use_identified=True):
-    """Constants of the ENV (not of a robot) that the identification touched.  stone_contact_radius: the radius around a stone's centre
-    within which a sole corner can touch it (docs/PHYSICS.md 3.3).  Rounds 1-4: 0.25 m = the reference's `step_radius`, which its
-    target / bonus logic uses; round 5 (steppingstone_amd/identified_env.json): the shipped policies of BOTH robots get
-    markedly further on non-flat terrain when the physical stepping surface is larger than that disc, as the reference's plank-shaped
-    step bodies would be.  The 0.25 m of the step bonus and the target logic (PHYSICS.md 4.5) is unchanged."""
+    """Constants of the ENV (not of a robot) that the identification touched: the stones' STEPPING SURFACE (docs/PHYSICS.md 3.3).
+    Rounds 1-4: a disc of 0.25 m = the reference's `step_radius`, which its target / bonus logic uses; round 5: a disc of 0.45 m (the
+    shipped policies of both robots get markedly further when the physical surface is larger than that disc) -- whose neighbours
+    overlap at the stones' spacing.  Round 6: a PLANK, as SURVEY section 9 recollects the reference's step bodies: footprint
+    2 x half_length along the stone's heading by 2 x half_width across it; half_length 0.30 m is the longest plank that cannot overlap
+    its neighbour at the smallest stone spacing (0.65 m), the half-width is identified (steppingstone_amd/identified_env.json).  The 0.25 m
+    of the step bonus (PHYSICS.md 4.5) is unchanged."""
     import json
     import os
-    c = {"stone_contact_radius": 0.25}
+    c = {"stone_plank_half_length": 0.30, "stone_plank_half_width": 0.40}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "identified_env.json")
     if use_identified and os.path.exists(path):
         c.update(json.load(open(path))["constants"])

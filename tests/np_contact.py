@@ -18,7 +18,9 @@ import np_dynamics as npd
 from steppingstone_amd import model as M
 
 H = npd.H_SUB
-STONE_R, REACH, ERP, SLOP, VCORR_MAX, SWEEPS = float(np.float32(M.env_constants()["stone_contact_radius"])), 0.10, 0.2, 0.001, 2.0, 5
+PLANK_A = float(np.float32(M.env_constants()["stone_plank_half_length"]))       # the stones' stepping surface (PHYSICS.md 3.3): a plank,
+PLANK_B = float(np.float32(M.env_constants()["stone_plank_half_width"]))        # 2 PLANK_A along the stone's heading x 2 PLANK_B across it
+REACH, ERP, SLOP, VCORR_MAX, SWEEPS = 0.10, 0.2, 0.001, 2.0, 5
 FEET = (M.RIGHT_FOOT_BODY, M.LEFT_FOOT_BODY)
 
 
@@ -67,13 +69,14 @@ def detect(m, pos, quat, q, terrain, n):
                 st = terrain[si]
                 nrm = stone_normal(st)
                 d = float((P - st[:3]) @ nrm)
-                rho = np.linalg.norm((P - st[:3]) - d * nrm)
-                touch = -REACH < d < 0 and rho < STONE_R
-                on_target = on_target or (touch and sl == 1)       # touches stone n, whichever stone carries the corner
+                l = (P - st[:3]) - d * nrm                         # in-plane offset; its horizontal part along / across the heading
+                heading = np.array([np.cos(st[3]), np.sin(st[3])])
+                u, v = l[:2] @ heading, l[:2] @ np.array([-heading[1], heading[0]])
+                touch = -REACH < d < 0 and abs(u) < PLANK_A and abs(v) < PLANK_B
                 if touch and d < best:                             # the deeper stone wins; ties go to the lower slot
                     best, hit = d, dict(r=r, stone=si, n=nrm, pen=-d, foot=f, Rf=R[b])
             if hit is not None:
-                hit["on_target"] = on_target
+                hit["on_target"] = hit["stone"] == idx[1]          # on the target: a corner CARRIED by stone n
             out.append(hit)
     return out
 

@@ -93,7 +93,7 @@ def control_step(m, st, act):
     for c in contacts:
         if c is not None:
             flags |= 1 << c["foot"]
-            on_target |= bool(c["on_target"])          # a corner within stone n's contact disc, whichever stone carries it
+            on_target |= bool(c["on_target"])          # a corner carried by stone n (np_contact.detect)
     elapsed += 1
     pos = st[POS]
     step_bonus, advance = 0.0, False

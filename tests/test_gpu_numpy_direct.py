@@ -62,7 +62,7 @@ def numpy_sensitivity(m, st, act, ref):
 
 def detection_margin(m, st):
     """Distance of the nearest sole corner to a switching surface of the detection (PHYSICS.md 3.3): plane distance 0 or -reach,
-    disc radius, two touching stones at the same depth -- evaluated like np_contact.detect does."""
+    the plank's edges, two touching stones at the same depth -- evaluated like np_contact.detect does."""
     pos, quat, q = st[0:3], st[3:7], st[13:34]
     terrain = st[65:185].reshape(20, 6)
     n = int(st[59])
@@ -78,10 +78,12 @@ def detection_margin(m, st):
             for si in (max(n - 1, 0), n, min(n + 1, 19)):
                 nrm = npc.stone_normal(terrain[si])
                 d = float((P - terrain[si][:3]) @ nrm)
-                rho = float(np.linalg.norm((P - terrain[si][:3]) - d * nrm))
-                if rho < npc.STONE_R + 1e-3 and -npc.REACH - 1e-3 < d < 1e-3:
-                    best = min(best, abs(d), abs(d + npc.REACH), abs(rho - npc.STONE_R))
-                if -npc.REACH < d < 0 and rho < npc.STONE_R:
+                l = (P - terrain[si][:3]) - d * nrm
+                c, s_ = np.cos(terrain[si][3]), np.sin(terrain[si][3])
+                u, v = float(l[0] * c + l[1] * s_), float(l[1] * c - l[0] * s_)
+                if abs(u) < npc.PLANK_A + 1e-3 and abs(v) < npc.PLANK_B + 1e-3 and -npc.REACH - 1e-3 < d < 1e-3:
+                    best = min(best, abs(d), abs(d + npc.REACH), abs(abs(u) - npc.PLANK_A), abs(abs(v) - npc.PLANK_B))
+                if -npc.REACH < d < 0 and abs(u) < npc.PLANK_A and abs(v) < npc.PLANK_B:
                     hits.append(d)
             for i in range(len(hits)):
                 for j in range(i):

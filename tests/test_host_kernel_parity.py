@@ -59,3 +59,44 @@ def test_target_advance_and_sampler_match_oracle():
         assert np.abs(rh - ro).max() < 2e-2
         adv |= io["update_terrain"].astype(bool)
     assert adv.mean() > 0.5
+
+
+@pytest.mark.parametrize("kind,k", [("walker3d", 0), ("mike", 1)])
+def test_steps_of_a_walking_policy_on_turned_and_tilted_stones_match_oracle(kind, k):
+    """Round 6: the stones' stepping surface is a plank aligned with the stone's HEADING, which the kernels carry as (cos, sin) per active
+    stone in fstate / LDS (reset, advance, set_state).  Random actions from the reset pose never leave the straight start of the course, so
+    here the reference's shipped actor walks the oracle at curriculum 3 until the stones in play are turned and tilted, and the kernel
+    source compiled for the host must then agree with the oracle step by step (contacts on, target advances included)."""
+    import torch
+    import host_lib as hl
+    import shipped_actor as sa
+    n = 48
+    o = ol.OracleEnv(kind, n, seed=21)
+    o.set_curriculum(3)
+    obs = o.reset()
+    actor = sa.load_actor(kind)
+    for t in range(170):
+        with torch.no_grad():
+            obs, _, _, _ = o.step(actor(torch.from_numpy(obs)).numpy())
+    st = o.get_state()
+    terr = st[:, 65:185].reshape(n, 20, 6)
+    nidx = st[:, ol.S_N].astype(int)
+    turned = np.abs(terr[np.arange(n), nidx, 3]) > 0.03
+    assert turned.sum() >= n // 8, "the sample does not exercise turned stones"      # (Mike falls early at this level: 8 of 48)
+    bad = total = advanced = contacts = 0
+    for t in range(14):
+        st = o.get_state()
+        with torch.no_grad():
+            a = actor(torch.from_numpy(o.get_obs())).numpy().astype(np.float32)
+        oo, ro, do, io = o.step(a)
+        so = o.get_state()
+        sh, oh, rh, dh, ih = hl.step(k, st, a, seed=21, curriculum=3)
+        ok = (np.abs(oh - oo).max(axis=1) < 2e-3) & ((np.abs(sh - so) / (2e-3 + 2e-3 * np.abs(so))).max(axis=1) < 1) & \
+             (np.abs(rh - ro) < 2e-2) & (dh == do) & (sh[:, INT_FIELDS] == so[:, INT_FIELDS]).all(axis=1) & \
+             (ih["update_terrain"] == io["update_terrain"])
+        bad += int((~ok).sum())
+        total += n
+        advanced += int(io["update_terrain"].sum())
+        contacts += int(((so[:, ol.S_FLAGS].astype(int) & 3) != 0).sum())
+    assert advanced >= 3 and contacts > total // 2, (advanced, contacts)
+    assert bad <= 0.02 * total, (bad, total)

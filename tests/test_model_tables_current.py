@@ -24,4 +24,5 @@ def test_identified_numbers_are_what_the_specification_evaluates():
         assert ident, "steppingstone_amd/identified_%s.json is missing" % kind
         m, prior = model.build(kind), model.build(kind, use_identified=False)
         assert abs(m["friction"] - ident["friction"]) < 1e-12 and m["mass"].sum() != prior["mass"].sum()
-    assert model.env_constants()["stone_contact_radius"] == 0.45 and model.env_constants(use_identified=False)["stone_contact_radius"] == 0.25
+    ec = model.env_constants()
+    assert ec["stone_plank_half_length"] == 0.30 and 0.30 <= ec["stone_plank_half_width"] <= 0.60      # a plank that cannot overlap its neighbour

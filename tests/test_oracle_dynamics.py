@@ -143,18 +143,20 @@ def test_resting_contact_is_bounded(kind):
     m = M.build(kind)
     env = ol.OracleEnv(kind, 1, seed=11, prec="f32")
     env.reset()
-    flags = None
+    flags, both = None, 0
     for k in range(12):           # 12 x 4 substeps = 0.2 s
         flags = env.substeps(0, np.zeros(21), 4)
+        both += int(flags[0] == 1 and flags[1] == 1)
         st = env.get_state()[0].astype(np.float64)
         pos, rot = ol.debug_fk(kind, st)
-        rc = M.env_constants()["stone_contact_radius"]
+        ec = M.env_constants()
         for b in (M.RIGHT_FOOT_BODY, M.LEFT_FOOT_BODY):
             P = [pos[b] + rot[b] @ c for c in m["corners"]]
-            # corners over stone 0 (within its contact radius of the axis at the origin) are held by the contact model; a corner that
-            # hangs over the rim is not (the round-5 robot's reset crouch puts its heels near the rim of a 0.25 m stone)
-            zc = [p[2] for p in P if np.hypot(p[0], p[1]) < rc - 0.005]
+            # corners over stone 0 (inside its plank footprint around the origin, heading +x) are held by the contact model; a corner
+            # that hangs over the rim is not
+            zc = [p[2] for p in P if abs(p[0]) < ec["stone_plank_half_length"] - 0.005 and abs(p[1]) < ec["stone_plank_half_width"] - 0.005]
             assert len(zc) >= 2 and min(zc) > -0.012, (k, b, zc)
         assert np.isfinite(st).all()
         assert np.abs(st[ol.S_VEL]).max() < 10 and np.abs(st[ol.S_QD]).max() < 60
-    assert flags[0] == 1 and flags[1] == 1
+    # both feet carry the robot while it stands; as the passive body sags one sole may peel off the 0.6 m long plank before 0.2 s are over
+    assert both >= 6 and (flags[0] == 1 or flags[1] == 1), (both, flags)

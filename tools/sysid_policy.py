@@ -244,7 +244,9 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False, polic
     lib.sso_debug_set_stone_radius.argtypes = [C.c_double]
     lib.sso_debug_set_plank.argtypes = [C.c_double, C.c_double]
     lib.sso_debug_set_dr.argtypes = [C.c_double, C.c_double]
-    lib.sso_debug_set_stone_radius(float(stone_r) if stone_r is not None else SPEC_STONE_RADIUS)
+    # round 6: the specification's stepping surface is the PLANK of the tables; a stone radius (a rounds-1-5 search space, a disc
+    # variant of the scan) switches the oracle to its disc study mode
+    lib.sso_debug_set_stone_radius(float(stone_r) if (stone_r is not None and "plank" not in env) else 0.0)
     lib.sso_debug_set_plank(*[float(v) for v in env.get("plank", (0.0, 0.0))])
     lib.sso_debug_set_dr(*[float(v) for v in env.get("dr", (0.65, 0.6))])
     lib.sso_debug_set_target_rule(int(env.get("target_carried", TARGET_CARRIED)))
@@ -288,7 +290,7 @@ def rollout(kind, ov, n=64, steps=500, seed=9, curriculum=0, detail=False, polic
     return score
 
 
-TARGET_CARRIED = 0       # --target-carried: on-target only through a corner that stone n carries (the round-6 rule)
+TARGET_CARRIED = 1       # --target-carried 0: the rounds-1-5 on-target rule (a corner within stone n's surface, whichever stone carries it)
 FIXED_STONE_RADIUS = 0.0 # --stone-radius in a search: the coordinate is frozen at this value
 SPEC_STONE_RADIUS = 0.25 # what a model without an "env.stone_radius" override is evaluated with
 STEPS = 500              # --steps: control steps per evaluation episode
@@ -367,13 +369,11 @@ def scan(args, S, names, std):
         best = json.load(open(args.scan))
         x = np.array([best["x"].get(n, 0.0) for n in names])
         ov, use_id = overrides_of(args.kind, x * std, S), False
-    r_spec = ov.get("env.stone_radius", None)
-    if r_spec is None:
-        from steppingstone_amd import model
-        r_spec = model.env_constants()["stone_contact_radius"]
-    plank = ov.get("env.plank")
-    base_env = {"plank": plank} if plank else {"stone_radius": r_spec}
-    variants = [("as specified (%s)" % ("plank %.2f x %.2f" % tuple(plank) if plank else "disc R_c = %.3f" % r_spec), {}),
+    from steppingstone_amd import model
+    ec = model.env_constants()
+    plank = ov.get("env.plank") or (ec["stone_plank_half_length"], ec["stone_plank_half_width"])
+    base_env = {"plank": plank}
+    variants = [("as specified (plank %.2f x %.2f)" % tuple(plank), {}),
                 ("INFINITE PLANE for contact, target logic on a 0.45 disc", {"stone_radius": 1000.0, "target_radius": 0.45}),
                 ("disc R_c = 0.25", {"stone_radius": 0.25}), ("disc R_c = 0.30", {"stone_radius": 0.30}), ("disc R_c = 0.325", {"stone_radius": 0.325}),
                 ("disc R_c = 0.40", {"stone_radius": 0.40}), ("disc R_c = 0.45", {"stone_radius": 0.45}), ("disc R_c = 0.55", {"stone_radius": 0.55}),
@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--prior", type=float, default=0.0, help="L2 pull towards the specification's defaults (per mean squared std)")
     ap.add_argument("--sigma0", type=float, default=0.0)
     ap.add_argument("--plausible", action="store_true", help="round 6: the bounded space (space_plausible) and its projections")
-    ap.add_argument("--target-carried", type=int, default=0, help="1: the round-6 on-target rule (a corner CARRIED by stone n)")
+    ap.add_argument("--target-carried", type=int, default=1, help="0: the rounds-1-5 on-target rule (study)")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--scan", default="", help="terrain / contact study of a *_best.json ('spec' = the compiled-in specification): "
                     "contact radius, infinite plane, plank shapes, stone spacing, on-target rule x curricula x policies")
