@@ -437,7 +437,8 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
       m3v(&w->Rw[b], c->r, P);
       for (int i = 0; i < 3; ++i) { P[i] += w->pw[b][i]; fr->sole[f][i] += (real)0.25 * P[i]; }
       real best = 0;
-      for (int sl = 0; sl < 3; ++sl) {
+      for (int si = 0; si < 3; ++si) {
+        const int sl = si == 0 ? 1 : (si == 1 ? 0 : 2);   /* the target stone n first: it wins an exact tie, then n-1, then n+1 */
         const real* st = s->terrain[idx[sl]];
         real nrm[3], dv[3] = {P[0] - st[0], P[1] - st[1], P[2] - st[2]};
         stone_normal(st, nrm);
@@ -453,7 +454,7 @@ static void detect(const sso_model* M, const env_state* s, const work* w, contac
         /* rounds 1-5 (study only): on the target when a corner touches stone n, whichever stone carries that corner */
         if (touch && sl == 1 && !g_target_carried && (g_target_r <= 0 || rho2 < g_target_r * g_target_r)) fr->foot_on_target[f] = 1;
         /* two touching stones: the deeper one wins (a first touching stone always does, also when its predicate was
-         * forced against d >= 0); an exact tie between COPLANAR stones goes to the lower slot and is not a decision -- either
+         * forced against d >= 0); an exact tie between COPLANAR stones goes to the stone visited first (n, n-1, n+1) and is not a decision -- either
          * winner gives the same normal and the same depth */
         int coplanar_tie = c->active && d == best && nrm[0] == c->n[0] && nrm[1] == c->n[1] && nrm[2] == c->n[2];
         int wins = decide(0, !c->active || d < best, (touch && c->active && !coplanar_tie) ? d - best : FAR_MARGIN);

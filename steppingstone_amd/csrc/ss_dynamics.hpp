@@ -581,7 +581,8 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
       float best = 0.f;
       int slot = -1;
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) {
+      for (int si = 0; si < 3; ++si) {
+        const int sl = si == 0 ? 1 : (si == 1 ? 0 : 2);      // the target stone n first: it wins an exact tie (then n-1, then n+1)
         float dx = P[0] - sp[sl][0], dy = P[1] - sp[sl][1], dz = P[2] - sp[sl][2];
         float d = dx * sn_[sl][0] + dy * sn_[sl][1] + dz * sn_[sl][2];
         float lx = dx - d * sn_[sl][0], ly = dy - d * sn_[sl][1], lz = dz - d * sn_[sl][2];
@@ -589,7 +590,7 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
         // the plank's footprint seen from above: the horizontal components of the in-plane offset along / across the stone's heading
         const float u = lx * hc[sl] + ly * hs_[sl], v = ly * hc[sl] - lx * hs_[sl];
         const bool touch = (d < 0.f) && (d > -0.10f) && (fabsf(u) < kPlankA) && (fabsf(v) < kPlankB);
-        if (touch && d < best) { best = d; slot = sl; }      // the deeper stone wins, an exact tie goes to the lower slot
+        if (touch && d < best) { best = d; slot = sl; }      // the deeper stone wins, an exact tie goes to the stone visited first
       }
       o.pen[k] = -best;
       // on the target = a corner CARRIED by stone n (round 6; rounds 1-5: within stone n's disc, whichever stone carried it)

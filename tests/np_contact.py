@@ -65,7 +65,8 @@ def detect(m, pos, quat, q, terrain, n):
                 r[1] = -r[1]
             P = p[b] + R[b] @ r
             best, hit, on_target = 0.0, None, False
-            for sl, si in enumerate(idx):
+            for sl in (1, 0, 2):                                   # the target stone n first: it wins an exact tie, then n-1, then n+1
+                si = idx[sl]
                 st = terrain[si]
                 nrm = stone_normal(st)
                 d = float((P - st[:3]) @ nrm)
@@ -73,7 +74,7 @@ def detect(m, pos, quat, q, terrain, n):
                 heading = np.array([np.cos(st[3]), np.sin(st[3])])
                 u, v = l[:2] @ heading, l[:2] @ np.array([-heading[1], heading[0]])
                 touch = -REACH < d < 0 and abs(u) < PLANK_A and abs(v) < PLANK_B
-                if touch and d < best:                             # the deeper stone wins; ties go to the lower slot
+                if touch and d < best:                             # the deeper stone wins; an exact tie goes to the stone visited first
                     best, hit = d, dict(r=r, stone=si, n=nrm, pen=-d, foot=f, Rf=R[b])
             if hit is not None:
                 hit["on_target"] = hit["stone"] == idx[1]          # on the target: a corner CARRIED by stone n

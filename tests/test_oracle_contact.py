@@ -227,3 +227,49 @@ def test_parity_rule_accepts_the_oracle_and_rejects_injected_errors():
         assert (r["e_pose"] == 0).all() and (r["e_vel"] == 0).all()
         st = r["next_state"]
     assert caught >= 10
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_a_corner_over_two_planks_is_carried_by_the_deeper_one(kind):
+    """ADVICE r5 (the overlap lens): two neighbouring stepping surfaces can both hold a sole corner only where a TURNED plank's corner
+    reaches over its neighbour (half-length 0.30 m <= half the smallest spacing).  Build exactly that on tilted terrain -- stone 1 only
+    0.65 m from stone 0's far end is not enough, so it is pulled to 0.50 m, turned by 20 degrees and both are tilted (the curricula-3 / 5
+    ranges) -- stand the robot over the seam and require of the oracle, against the independent numpy detection: the same winner per
+    corner ('deeper wins', ties to the lower slot), the winner's normal and depth, and 'on target' only through corners that stone n
+    itself carries."""
+    m = npc.rounded_model(kind)
+    rng = np.random.default_rng(5)
+    deg = np.pi / 180
+    one = ol.OracleEnv(kind, 1, seed=0, prec="f64")
+    one.reset()
+    base = one.get_state()[0].copy()
+    both = winners = on_target_cases = 0
+    for trial in range(400):
+        st = base.copy()
+        terrain = st[ol.S_TERRAIN].reshape(20, 6)
+        terrain[0, 3] = rng.uniform(-20, 20) * deg
+        terrain[0, 4:6] = rng.uniform(-15, 15, 2) * deg
+        terrain[1, 0:3] = [rng.uniform(0.42, 0.58), rng.uniform(-0.08, 0.08), rng.uniform(-0.01, 0.01)]
+        terrain[1, 3] = terrain[0, 3] + rng.choice([-1, 1]) * rng.uniform(12, 20) * deg
+        terrain[1, 4:6] = rng.uniform(-15, 15, 2) * deg
+        st[ol.S_POS] = [rng.uniform(0.15, 0.40), rng.uniform(-0.25, 0.25), st[ol.S_POS][2] + rng.uniform(-0.03, 0.0)]
+        n = int(rng.integers(0, 2))                   # target = stone 0 (active: 0, 0, 1) or stone 1 (active: 0, 1, 2)
+        st[ol.S_N] = n
+        ref = npc.detect(m, st[ol.S_POS], st[ol.S_QUAT], st[ol.S_Q], terrain, n)
+        one.set_state(st[None])
+        tap = one.debug_contact(0, np.zeros(21))
+        active = tap["active"].astype(bool)
+        assert np.array_equal(active, np.array([c is not None for c in ref])), trial
+        for k in np.nonzero(active)[0]:
+            assert tap["stone"][k] == ref[k]["stone"], (trial, k)
+            assert np.abs(tap["nrm"][k] - ref[k]["n"]).max() < 1e-12 and abs(tap["pen"][k] - ref[k]["pen"]) < 1e-12
+        one.set_state(st[None])                         # (the tap above ran the substep)
+        flags4 = one.substeps(0, np.zeros(21), 1)       # [contact R, contact L, on-target R, on-target L] of the detector
+        on_t = [any(c is not None and c["foot"] == f and c["on_target"] for c in ref) for f in (0, 1)]
+        assert [int(flags4[2]), int(flags4[3])] == [int(x) for x in on_t], (trial, flags4, on_t)
+        stones = {c["stone"] for c in ref if c is not None}
+        both += len(stones) == 2
+        winners += sum(c is not None for c in ref)
+        on_target_cases += any(on_t)
+    print("%s: %d of 400 stances stand on both planks at once (%d carried corners), %d with a foot on the target" % (kind, both, winners, on_target_cases))
+    assert both >= 40 and on_target_cases >= 100
