@@ -636,6 +636,8 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
     from steppingstone_amd import ppo
     from steppingstone_amd.envs import SteppingStoneVecEnv
     U, T, MB = max(5, args.updates), 32, 1024
+    # test transport only (tests/test_gpu_configs4.py): fewer PPO epochs per update, stated in the line; a real run is always 10
+    EPOCHS = int(os.environ.get("SS_BENCH_TEST_PPO_EPOCHS", "10")) if os.environ.get("SS_BENCH_TEST_TRANSPORT") else 10
     # "minibatch 1024 kept or scaled -- state the choice".  Both, torch learner: row A keeps the reference's minibatch of
     # 1024 (playground/train.py:62; 128 minibatches per epoch of this rank's 131 072-frame rollout), row B keeps the reference's NUMBER
     # of minibatches per epoch instead (train.py:63: 40000 // 1024 = 39; the nearest divisor of the rollout is 32 -> minibatch 4096).
@@ -656,7 +658,7 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
             if use_dist:
                 dist.barrier()
             t0 = time.perf_counter()
-            ppo.train(envs, U, num_steps=T, ppo_epoch=10, mini_batch_size=mb, use_curriculum=True, log=log)
+            ppo.train(envs, U, num_steps=T, ppo_epoch=EPOCHS, mini_batch_size=mb, use_curriculum=True, log=log)
             torch.cuda.synchronize(dev)
             if use_dist:
                 dist.barrier()
@@ -685,6 +687,7 @@ def ppo_e2e(args, torch, dist, dev, rank, world, use_dist, n_local):
                                    "reference's ~39 minibatches per epoch kept instead (train.py:63), i.e. minibatch %d" % MB_SCALED,
                "note": "random-init weights, synthetic rollouts of the env itself; the value is the torch-learner row A"}
         if os.environ.get("SS_BENCH_TEST_TRANSPORT"):
+            out["config"]["test_ppo_epochs"] = EPOCHS
             out["config"]["test_transport"] = ("%s, all %d ranks on cuda:0 -- a FUNCTIONAL run of the N > 1 path on a one-GPU box, never a "
                                                "measurement" % (os.environ["SS_BENCH_TEST_TRANSPORT"], world))
         out["transport"] = os.environ.get("SS_BENCH_TEST_TRANSPORT") or ("nccl" if use_dist else "none")
