@@ -115,7 +115,7 @@ def space_plausible(kind="walker3d"):
 PLANK_A = 0.30
 FIXED_PLANK_B = 0.0
 PLAUSIBLE = False        # --plausible: the bounded space above + the projections in overrides_of
-Q0_MARGIN_DEG = 4.0
+Q0_MARGIN_DEG = 4.05            # 0.0707 rad >= the reset clip margin 0.02 + the reset noise half-width 0.05 (PHYSICS.md 7)
 
 
 def overrides_of(kind, x, S):
@@ -310,8 +310,10 @@ PRIOR = 0.0              # --prior: penalty per unit of |x|^2 / n (x in units of
 def _eval(args):
     x, S = args
     ov = overrides_of(_W["kind"], x, S)
-    sc = float(np.mean([rollout(_W["kind"], ov, n=64 if len(CURRICULA) == 1 else (48 if len(CURRICULA) < 4 else 40), steps=STEPS, seed=9 + 100 * c,
-                                curriculum=c) for c in CURRICULA]))
+    # an entry of CURRICULA is a level, or ("base", level): the same terrain under the reference's OTHER shipped Walker3D actor
+    cells = [(c[0], c[1]) if isinstance(c, tuple) else ("latest", c) for c in CURRICULA]
+    sc = float(np.mean([rollout(_W["kind"], ov, n=64 if len(cells) == 1 else (48 if len(cells) < 4 else 40), steps=STEPS, seed=9 + 100 * c,
+                                curriculum=c, policy=pol) for pol, c in cells]))
     if PRIOR:
         std = np.array([s_[2] for s_ in S])
         sc -= PRIOR * float(np.mean((np.asarray(x) / std) ** 2))
@@ -447,7 +449,7 @@ def main():
     PLAUSIBLE, TARGET_CARRIED, STEPS, FIXED_PLANK_B = args.plausible, args.target_carried, args.steps, args.plank_b
     if args.stone_radius and not (args.emit or args.evaluate or args.ablate):
         FIXED_STONE_RADIUS = args.stone_radius
-    CURRICULA = [int(c) for c in args.curricula.split(",")]
+    CURRICULA = [("base", int(c[1:])) if c.startswith("b") else int(c) for c in args.curricula.split(",")]
     PRIOR = args.prior
     S = space_plausible(args.kind) if PLAUSIBLE else space()
     names = [s[0] for s in S]
