@@ -4,15 +4,15 @@ Every other `-m gpu` parity test samples random-action states; the only state cl
 4: Mike standing on two sole corners, profiles/r05_v1d_parity_heldout_miss_diagnosis.txt) was a WALKING policy's, and until round 6 that
 class was judged only by the builder-run tools/parity_heldout.py.  Here the reference's shipped deterministic actors
 (tests/golden/shipped_actor_<kind>.npz, plain arrays: /root/reference does not exist on the GPU box) walk the HIP env for 300 control
-steps in 1024 envs -- stepping onto stones, standing, stumbling, auto-resets -- at curricula 0 and 3; from the states they are then in, 20
+steps in 1024 envs per robot (512 at each curriculum) -- stepping onto stones, standing, stumbling, auto-resets -- at curricula 0 and 3; from the states they are then in, 20
 control steps under the policy's own actions are each judged by parity_rule.StepJudge (version 3: integers exact, every quantity inside
 max(floor, 8 s), near-threshold decisions matched on some branch) and the sample must meet every threshold of
 parity_assert.assert_judged.  HIP through the C ABI (ss_set_state / ss_step / ss_get_state) against the CPU oracle on the same injected
-state and the same action, 4 cells x 20 480 env-steps.
+state and the same action, 4 cells x 10 240 env-steps.
 
 What is asserted where (as tools/parity_heldout.py does): every CELL must be free of failures -- every env-step inside its bound, integers
 exact; the thresholds about the COMPOSITION of a sample (share of plain env-steps, bounds' quantiles, `loose` bounds < 1 %, the err / bound
-quantile) are asserted on the union of the four cells, 81 920 env-steps.  The first GPU run of this file (profiles/r06_a_pytest_gpu.log)
+quantile) are asserted on the union of the four cells, 40 960 env-steps.  The first GPU run of this file (profiles/r06_a_pytest_gpu.log; 1024 envs per cell then)
 had asserted them per cell: 0 failures everywhere, and the Mike / curriculum-3 cell -- where that policy falls after 3.9 stones, 1741
 episodes ending within the 300 harvest steps -- carried `loose` bounds on 1.25 % of its env-steps against the rule's 1 % (a property of
 the fp64 sensitivity of a falling robot's states, measured without looking at the HIP result); the rule's LOOSE_MAX_FRACTION is frozen and
@@ -26,7 +26,7 @@ import shipped_actor as sa
 
 torch = pytest.importorskip("torch")
 
-WALK_STEPS, JUDGED_STEPS, N = 300, 20, 1024
+WALK_STEPS, JUDGED_STEPS, N = 300, 20, 512          # 1024 envs per robot: 512 at each of the two curricula
 CELLS = [("Walker3DStepperEnv-v0", "walker3d", 0), ("Walker3DStepperEnv-v0", "walker3d", 3),
          ("MikeStepperEnv-v0", "mike", 0), ("MikeStepperEnv-v0", "mike", 3)]
 
