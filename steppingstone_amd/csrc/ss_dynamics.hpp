@@ -681,6 +681,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     SS_FUZZ(0x20u + helper);
   }
   float rowdir[12][3], rowB[4];       // helper 0: directions of the contact rows, Baumgarte terms
+  DetectOut det0;                     // helper 0: what the detection found (kept in registers across barrier #1)
   if (helper == 0) {
     float cs8[8], sn8[8];
     float quat[4] = {L.s(S_QUAT), L.s(S_QUAT + 1), L.s(S_QUAT + 2), L.s(S_QUAT + 3)};
@@ -712,12 +713,8 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
         for (int c = 0; c < 3; ++c) L.hs(kHandDet + a * 3 + c) = det.Rf[a][c];
 #pragma unroll
       for (int k = 0; k < 4; ++k) L.hs(kHandDet + 9 + k) = det.pen[k];
-    } else {                           // the rows' directions stay in registers until the leg records' place is free (after #2)
-      ssf2 rWp[12][3];
-      jacobian_rows<Model>(det, L, rWp, rowB);
-#pragma unroll
-      for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
     }
+    det0 = det;
   }
   if constexpr (bias_offload(HELPERS)) {
     if (helper == 1) {                 // spine velocities from the base twist, then the bias forces of bodies 1..3 and 0
@@ -746,6 +743,17 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
   extra(helper);
   __syncthreads();                                   // #1: leg joint records are in the hand-off region
   SS_FUZZ(0x30u + helper);
+  if constexpr (rows_offload(HELPERS)) {
+    // the rows' directions (round 6: moved here from the window before #1, where helper 0's kinematics + detection + rows were the
+    // longest path of the workgroup; between #1 and #2 the helpers' part A is a third of the main wavefront's spine window).  They stay
+    // in registers until the leg records' place is free (after #2)
+    if (helper == 0) {
+      ssf2 rWp[12][3];
+      jacobian_rows<Model>(det0, L, rWp, rowB);
+#pragma unroll
+      for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
+    }
+  }
   JointCache jin, jc;
   static_for<3, 8>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;

@@ -773,6 +773,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   float target_old[3] = {c.p[1][0], c.p[1][1], c.p[1][2]};
   float step_bonus = 0.f;
   int advanced = 0;
+  float hd[3][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};      // headings of the active stones, true world: meaningful after an advance / a reset only
   if (on_target != 0) {
     count += 1;
     if (count == 1) {
@@ -790,12 +791,17 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       }
       c.tilt[0][0] = c.tilt[1][0]; c.tilt[0][1] = c.tilt[1][1];
       c.tilt[1][0] = c.tilt[2][0]; c.tilt[1][1] = c.tilt[2][1];
-      // the headings move with the stones: in the lane's LDS (its own world), slot 2 from the draw (at n = 19 it keeps the last stone's)
-      float hnew[2] = {L.q2(kLdsHead + 2).x, m * L.q2(kLdsHead + 2).y};
-      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, K, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], hnew, valid && side == 0);
-      L.q2(kLdsHead + 0) = L.q2(kLdsHead + 1);
-      L.q2(kLdsHead + 1) = L.q2(kLdsHead + 2);
-      L.q2(kLdsHead + 2) = make_float2(hnew[0], m * hnew[1]);
+      // the headings move with the stones: slot 2 from the draw (at n = 19 it keeps the last stone's).  hd[] is the TRUE-world copy that
+      // the write-back below stores; the lane's LDS holds its own (y-mirrored) world.  LDS is read here only: a target advance is rare,
+      // a reset is not, and the write-back path must not wait for LDS
+      const float2 h1 = L.q2(kLdsHead + 1), h2 = L.q2(kLdsHead + 2);
+      hd[0][0] = h1.x; hd[0][1] = m * h1.y;
+      hd[1][0] = h2.x; hd[1][1] = m * h2.y;
+      hd[2][0] = h2.x; hd[2][1] = m * h2.y;
+      if (n + 1 <= kNumStones - 1) nn_dr = draw_stone(P, K, e, ctr, n + 1, c.p[2], c.nrm[2], c.tilt[2], hd[2], valid && side == 0);
+      L.q2(kLdsHead + 0) = h1;
+      L.q2(kLdsHead + 1) = h2;
+      L.q2(kLdsHead + 2) = make_float2(hd[2][0], m * hd[2][1]);
     }
   }
   // 6. progress
@@ -846,6 +852,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
       c.p[sl][0] = 0.75f * (float)sl; c.p[sl][1] = 0.f; c.p[sl][2] = 0.f;
       c.nrm[sl][0] = 0.f; c.nrm[sl][1] = 0.f; c.nrm[sl][2] = 1.f;
       c.tilt[sl][0] = 0.f; c.tilt[sl][1] = 0.f;
+      hd[sl][0] = 1.f; hd[sl][1] = 0.f;
       L.q2(kLdsHead + sl) = make_float2(1.f, 0.f);
     }
     pos[0] = 0.f; pos[1] = 0.f; pos[2] = Model::stand_height + 0.01f;
@@ -930,8 +937,6 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     float* Fo = P.fstate + e;
     if (advanced || do_reset) {
       store_cache(P, e, c);
-      const float hd[3][2] = {{L.q2(kLdsHead).x, L.q2(kLdsHead).y}, {L.q2(kLdsHead + 1).x, L.q2(kLdsHead + 1).y},
-                              {L.q2(kLdsHead + 2).x, L.q2(kLdsHead + 2).y}};      // side 0: its world is the true one
       store_headings(P, e, hd);
     }
     gst<!ROLLOUT>(&Fo[F_POT * np], pot_prev);
