@@ -70,6 +70,13 @@ constexpr bool bias_offload(int helpers) { return helpers >= 3; }
 constexpr int kHandBias = kHandJc;
 static_assert(24 <= 3 * 9, "biases fit the spine records' place");
 constexpr int kHandRows = kHandJc + 3 * 9;
+// Three-helper variants (at most 8192 envs: one workgroup per CU): the rows get a place of their own behind the region, so that
+// helper 0 can write them BEFORE barrier #2 (as soon as it has them, round 6) and the main wavefront can fetch them and form their
+// moment parts while it waits at barrier #3 for the operators instead of after it.
+constexpr int kHandRows3 = 160;
+constexpr int kHandFloats3 = kHandRows3 + 40;
+constexpr int kHandSlots3 = (kHandFloats3 + 3) / 4;
+constexpr int hand_slots(int helpers) { return helpers >= 3 ? kHandSlots3 : (kHandFloats + 3) / 4; }
 // ... with three helpers; a single helper is the critical path in its windows already (16384 envs: 0.0676 vs 0.0609 ms/step)
 constexpr bool rows_offload(int helpers) { return helpers >= 3; }
 constexpr int kHandSlots = (kHandFloats + 3) / 4;  // float4-slots per lane
@@ -86,6 +93,10 @@ static_assert(S_END <= (kLdsSlots - kSlotsA) * 4, "LDS scalar region overflow");
 // Where the warm-start impulses live between the substeps of a control step: in registers where there is room (three helper
 // wavefronts: 192 - 205 of 256 AGPRs), in the lane's LDS scalars otherwise (the plain and the one-helper rollout kernels sit at
 // 252 - 255 AGPRs and would spill 20 - 40 B per lane; 13 ds_write + 13 ds_read per substep instead).  Values are the same either way.
+#ifndef SS_CS_PER_HELPER
+#define SS_CS_PER_HELPER 6      // three-helper variants: 6 = helpers 1 and 2 evaluate six cos / sin pairs each, helper 0 idles; 4 = all three
+                                // take four each (ss_rollout3.hip sets it for the rollout kernel: measured per kernel, see there)
+#endif
 #ifndef SS_WARM_LDS_BELOW
 #define SS_WARM_LDS_BELOW 3
 #endif
@@ -211,6 +222,13 @@ SSD float xchg(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 #else
   return ss_host_xchg(x);
+#endif
+}
+SSD uint32_t xchg_u32(uint32_t x) {      // all 32 bits, unchanged (random words)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+#else
+  return __builtin_bit_cast(uint32_t, ss_host_xchg(__builtin_bit_cast(float, x)));
 #endif
 }
 SSD int xchg_i(int x) {
@@ -664,10 +682,11 @@ template <class Model, int HELPERS, class Extra>
 __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&& extra) {
   __syncthreads();                                   // #0
   SS_FUZZ(0x10u + helper);
-  if constexpr (cs_offload(HELPERS)) {   // cos / sin of the 12 joint angles for everybody: helpers 1 and 2 take six each
-    constexpr int kPer = HELPERS >= 3 ? 6 : NH;
-    const int first = HELPERS >= 3 ? (helper - 1) * 6 : 0;
-    if (HELPERS < 3 || helper >= 1) {
+  if constexpr (cs_offload(HELPERS)) {   // cos / sin of the 12 joint angles for everybody: helpers 1 and 2 six each, or (SS_CS_PER_HELPER
+                                         // = 4, the rollout kernel's unit) all three helpers four each
+    constexpr int kPer = HELPERS >= 3 ? SS_CS_PER_HELPER : NH;
+    const int first = HELPERS >= 3 ? (SS_CS_PER_HELPER == 4 ? helper * 4 : (helper - 1) * 6) : 0;
+    if (HELPERS < 3 || SS_CS_PER_HELPER == 4 || helper >= 1) {
       float qh[kPer], c_[kPer], s_[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; ++k) qh[k] = L.s(S_Q + first + k);
@@ -752,6 +771,12 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
       jacobian_rows<Model>(det0, L, rWp, rowB);
 #pragma unroll
       for (int row = 0; row < 12; ++row) { rowdir[row][0] = rWp[row][1].y; rowdir[row][1] = rWp[row][2].x; rowdir[row][2] = rWp[row][2].y; }
+#pragma unroll
+      for (int row = 0; row < 12; ++row)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) L.hs(kHandRows3 + row * 3 + i) = rowdir[row][i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) L.hs(kHandRows3 + 36 + k) = rowB[k];
     }
   }
   JointCache jin, jc;
@@ -769,14 +794,6 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
   });
   __syncthreads();                                   // #2: spine records and the base factor
   SS_FUZZ(0x40u + helper);
-  if (rows_offload(HELPERS) && helper == 0) {
-#pragma unroll
-    for (int row = 0; row < 12; ++row)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) L.hs(kHandRows + row * 3 + i) = rowdir[row][i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) L.hs(kHandRows + 36 + k) = rowB[k];
-  }
   static_for<0, 3>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value;
     JRec& r = jin.r[k];
@@ -842,7 +859,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
     });
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0);
+    SS_PROF(1);
     __syncthreads();                   // #0b: cos / sin are in the hand-off region
+    SS_PROF(12);                       // (tuning builds: the wait at barrier #0b)
     SS_FUZZ(0x2Fu);
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1037,7 +1056,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
         // the machine scheduler would otherwise pull the spine and the base solve in front of the barrier (it orders memory
         // operations only), and the helpers' part A would overlap nothing
         __builtin_amdgcn_sched_barrier(0);
+        SS_PROF(3);
         __syncthreads();               // #1
+        SS_PROF(14);                   // (tuning builds: the main wavefront's wait at barrier #1)
         SS_FUZZ(0x3Fu);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1121,7 +1142,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
 #pragma unroll
       for (int m = 0; m < 6; ++m) L.hs(kHandL0 + 15 + m) = jc.L0.di[m];
       __builtin_amdgcn_sched_barrier(0);
+      SS_PROF(4);
       __syncthreads();                 // #2
+      SS_PROF(15);                     // (tuning builds: the wait at barrier #2)
       SS_FUZZ(0x4Fu);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1241,6 +1264,21 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
         for (int i = 0; i < 3; ++i) { V[i] = a.w[i]; V[3 + i] = a.v[i]; }
       }
       if constexpr (!rows_offload(HELPERS)) jacobian_rows<Model>(det, L, rWp, rB);
+      if constexpr (rows_offload(HELPERS)) {
+        // the rows' directions and Baumgarte terms from helper 0 (written before barrier #2); the moment part here -- all of it while
+        // the helpers are still forming the operators (the main wavefront waited ~ 600 clocks per substep at barrier #3)
+        static_for<0, 12>([&](auto Rc) {
+          constexpr int row = decltype(Rc)::value;
+          float w[6];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) w[3 + i] = L.hs(kHandRows3 + row * 3 + i);
+          row_moment<Model, row / 3>(w);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
+        });
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rB[k] = L.hs(kHandRows3 + 36 + k);
+      }
   };
   auto solve = [&]() {              // y = Lambda w, PGS, response of the whole tree
       float ul[NH];
@@ -1271,20 +1309,6 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
         for (int b = 0; b < 6; ++b)
 #pragma unroll
           for (int i = 0; i < 3; ++i) Lc[b][i] = pkv(L.hs(kHandLc + b * 6 + 2 * i), L.hs(kHandLc + b * 6 + 2 * i + 1));
-      }
-      if constexpr (rows_offload(HELPERS)) {
-        // the rows' directions and Baumgarte terms from helper 0 (written after barrier #2); the moment part here
-        static_for<0, 12>([&](auto Rc) {
-          constexpr int row = decltype(Rc)::value;
-          float w[6];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) w[3 + i] = L.hs(kHandRows + row * 3 + i);
-          row_moment<Model, row / 3>(w);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) rWp[row][i] = ssf2{w[2 * i], w[2 * i + 1]};
-        });
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rB[k] = L.hs(kHandRows + 36 + k);
       }
       // rows (registers, float pairs): per (corner, direction) y = Lambda_own w, 1/A.  Inactive corners keep finite rows
       // (normal +z) and get 1/A = 0, b = 0, which freezes their lambda at 0.
@@ -1474,7 +1498,9 @@ SSD void substep(SS_PROF_DECL float power, FootReport& fr, const Lds& L, Warm& w
   } else {
     if (in_contact) rows_free();
 #if defined(__HIP_DEVICE_COMPILE__)
+    SS_PROF(8);
     __syncthreads();                 // #3: the helper wavefront(s) have written C, T and Lambda_own
+    SS_PROF(7);                      // (tuning builds, helper variants: the wait at barrier #3)
     SS_FUZZ(0x5Fu);
 #endif
     if (in_contact) solve();

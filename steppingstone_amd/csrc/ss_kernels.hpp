@@ -14,6 +14,9 @@
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
 #pragma once
 #include "ss_dynamics.hpp"
+#ifndef SS_EMIT_ON_LAST_HELPER
+#define SS_EMIT_ON_LAST_HELPER 1
+#endif
 #ifndef SS_NUM_SUBSTEPS
 #define SS_NUM_SUBSTEPS 4
 #endif
@@ -859,8 +862,23 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     quat[0] = 1.f; quat[1] = quat[2] = quat[3] = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { v0.w[i] = 0.f; v0.v[i] = 0.f; }
+    // the six Philox blocks of the reset noise: three per lane of the pair, exchanged (round 6: both lanes used to draw all six --
+    // 300 more instructions on every control step in which ANY of the wavefront's 32 envs resets, i.e. on 3 steps of 4 under random
+    // actions).  Integer-exact: the words are the ones env_block() would have produced.
+    {
+      uint32_t c3 = ctr + (side ? 3u : 0u), mine[3][4];
 #pragma unroll
-    for (int b = 0; b < 6; ++b) env_block(P, e, ctr, rr[b]);
+      for (int b = 0; b < 3; ++b) env_block(P, e, c3, mine[b]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t other = xchg_u32(mine[b][i]);
+          rr[b][i] = side ? other : mine[b][i];
+          rr[3 + b][i] = side ? mine[b][i] : other;
+        }
+      ctr += 6u;
+    }
     z_init = pos[2];
     nn_dr = 0.75f;
     pot_prev = -planar_dist(c.p[1], pos) / kDt;
@@ -1007,7 +1025,7 @@ template <class Model, bool RANDOM_ACT, int HELPERS>
 __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(Params P, StepIO io) {
   SS_PREFETCH_ENTRY();
   SS_PAD_ENTRY();
-  __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
+  __shared__ float4 lds4[(kLdsSlots + hand_slots(HELPERS)) * kWave];      // (three helpers: + the rows' own 40 words per lane)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
   SS_FUZZ(0x70u + wave);
@@ -1031,7 +1049,7 @@ template <class Model, int HELPERS>
 __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helped(Params P, StepIO io) {
   SS_PREFETCH_ENTRY();
   SS_PAD_ENTRY();
-  __shared__ float4 lds4[(kLdsSlots + kHandSlots) * kWave];
+  __shared__ float4 lds4[(kLdsSlots + hand_slots(HELPERS)) * kWave];      // (three helpers: + the rows' own 40 words per lane)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
   float* lds = reinterpret_cast<float*>(lds4);
   SS_FUZZ(0x70u + wave);
@@ -1052,10 +1070,14 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
           if (k != 0) return;
           SS_FUZZ(0x80u + helper);
           // the next control step's actions, while the main wavefront is in pass 1 / 2 of this step's first substep
-          if (HELPERS > 1 && helper == HELPERS - 1 && kstep + 1 < io.nsteps)
+          // (three helpers: helper 1 -- which also has the spine's bias forces in this window -- draws the actions, helper 2 has the
+          // longer job, the previous step's outputs, to itself; rounds 3-5 had them the other way round)
+          constexpr int kActHelper = SS_EMIT_ON_LAST_HELPER && out_offload(HELPERS, true) ? 1 : HELPERS - 1;
+          constexpr int kEmitHelper = SS_EMIT_ON_LAST_HELPER && out_offload(HELPERS, true) ? HELPERS - 1 : 1;
+          if (HELPERS > 1 && helper == kActHelper && kstep + 1 < io.nsteps)
             random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
           // the previous control step's outputs
-          if (out_offload(HELPERS, true) && helper == 1 && kstep > 0) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, kstep - 1, lds);
+          if (out_offload(HELPERS, true) && helper == kEmitHelper && kstep > 0) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, kstep - 1, lds);
         });
     if constexpr (out_offload(HELPERS, true)) {
       __syncthreads();                 // the last step's results are in the hand-off region

@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from steppingstone_amd import _lib
 from steppingstone_amd.envs import SteppingStoneVecEnv
-NAMES = ["loop/entry", "sincos", "pass1 vel", "pass2 ABI", "base chol", "pass3 acc", "detect FK", "Linv 12 cols",
-         "Vfree+rows", "PGS x8", "final resp", "integrate", "after loop", "reward/obs/store", "", ""]
+NAMES = ["loop/entry + wait #0", "torques (+ cs loads)", "pass1 vel", "pass2 ABI + spine", "base chol + hand-off", "pass3 acc", "detect FK / read",
+         "WAIT #3 (helper variants; else Linv)", "Vfree+rows", "PGS", "final resp", "integrate", "WAIT #0b", "reward/obs/store", "WAIT #1", "WAIT #2"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 spl = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # steps per launch (0: library default; 1: the one-launch-per-step kernel)
 steps = 200
