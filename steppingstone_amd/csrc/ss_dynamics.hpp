@@ -142,9 +142,17 @@ struct Prof { uint32_t t[16]; uint32_t last; };
 #define SS_PROF_DECL Prof& prof,
 #define SS_PROF_ARG prof,
 // wave-uniform accounting (readfirstlane keeps the counters in SGPRs, so divergent branches do not skew them)
-#define SS_PROF(i) do { uint32_t _n = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_amdgcn_s_memtime()); \
+#define SS_PROF_RAW(i) do { uint32_t _n = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_amdgcn_s_memtime()); \
     prof.t[i] = __builtin_amdgcn_readfirstlane(prof.t[i] + (_n - __builtin_amdgcn_readfirstlane(prof.last))); prof.last = _n; } while (0)
+#ifdef SS_PROFILE_EPILOGUE      // the substeps as one figure (slot 0), the control step's epilogue in detail (SS_PROFE, slots 1..15)
+#define SS_PROF(i) SS_PROF_RAW(0)
+#define SS_PROFE(i) SS_PROF_RAW(i)
 #else
+#define SS_PROF(i) SS_PROF_RAW(i)
+#define SS_PROFE(i) ((void)0)
+#endif
+#else
+#define SS_PROFE(i) ((void)0)
 struct Prof { int unused; };
 #define SS_PROF_DECL
 #define SS_PROF_ARG

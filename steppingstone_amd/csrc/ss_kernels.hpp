@@ -732,6 +732,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   float ep_ret = F[F_EPRET * np], ep_lo = F[F_EPRET_LO * np], nn_dr = F[F_NNDR * np];
   int n = P.istate[e + I_N * np], count = P.istate[e + I_COUNT * np], elapsed = P.istate[e + I_ELAPSED * np];
   uint32_t ctr = (uint32_t)P.istate[e + I_RNG * np];
+  SS_PROFE(1);       // address arithmetic + issue of the epilogue's global loads
 
   // 3-4. back to the true world; the pair shares its feet
   float pos[3] = {L.s(S_POS), m * L.s(S_POS + 1), L.s(S_POS + 2)};
@@ -748,6 +749,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   for (int i = 0; i < 3; ++i) { sole[0][i] = side ? ot_sole[i] : my_sole[i]; sole[1][i] = side ? my_sole[i] : ot_sole[i]; }
   int flags = side ? (ot_contact | (fr.contact << 1)) : (fr.contact | (ot_contact << 1));
   const int on_target = fr.on_target | ot_target;
+  SS_PROFE(2);       // LDS state read-back, pair exchange of the foot reports
   // partial sums over this lane's joints (the spine is counted by the right lane only)
   float accv = 0.f, e_sum = 0.f, a2 = 0.f;
   int at_limit = 0;
@@ -771,6 +773,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   a2 += xchg(a2);
   at_limit += xchg_i(at_limit);
   const bool finite = finite_bits(accv) && (xchg_i(finite_bits(accv) ? 1 : 0) != 0);
+  SS_PROFE(3);       // joint sums (energy, limits, finiteness)
 
   // 5. target logic
   float target_old[3] = {c.p[1][0], c.p[1][1], c.p[1][2]};
@@ -809,6 +812,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   }
   // 6. progress
   float pot = -planar_dist(target_old, pos) / kDt;
+  SS_PROFE(4);       // first use of the loaded scalars (wait for L2) + target logic (+ draw on advance)
   float progress = pot - pot_prev;
   pot_prev = advanced ? -planar_dist(c.p[1], pos) / kDt : pot;
   // 7-8
@@ -829,6 +833,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   float energy = (4.5f / NJ) * (e_sum / NJ) + (0.225f / NJ) * (a2 / NJ);
   float r = progress + step_bonus + target_bonus + tall_bonus - energy - posture - 0.1f * (float)at_limit;
   if (!finite || !finite_bits(r)) r = 0.f;
+  SS_PROFE(5);       // progress, termination, roll / pitch, reward
   {   // episode return as an unevaluated float pair (ep_ret, ep_lo): error-free two-sum of the step reward, then renormalised, so
       // that the pair carries the fp64 sum of the fp32 step rewards (Monitor.update sums Python floats, common/envs_utils.py:134)
     const float s = ep_ret + r, bb = s - ep_ret;
@@ -846,6 +851,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   inf.steps_reached = n;
   inf.update_terrain = advanced;
   const bool do_reset = d && K.auto_reset;
+  SS_PROFE(6);
   uint32_t rr[6][4];
   if (do_reset) {
     // PHYSICS.md section 7: provisional terrain (prov_from = 0: no table writes), standing pose, joint noise from 6 Philox blocks
@@ -884,6 +890,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     pot_prev = -planar_dist(c.p[1], pos) / kDt;
     n = 1; count = 0; elapsed = 0; flags = 0; ep_ret = 0.f; ep_lo = 0.f;
   }
+  SS_PROFE(7);       // reset branch (Philox blocks)
   // joint values of this lane in the TRUE world (after the optional reset)
   float qt[NH], qdt[NH];
   static_for<0, NH>([&](auto Kc) {
@@ -899,6 +906,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     }
   });
   // 11. output stage (emit_outputs): inline, or on helper 1 in the three-helper rollout kernel
+  SS_PROFE(8);       // joint values of the next state
   SS_FUZZ(0x62u);
   if constexpr (ROLLOUT || kOffload) {
     // the LDS copy of the state is what comes next (the next step, helper 1's output stage): refresh what the env logic changed
@@ -952,6 +960,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     emit_outputs<Model, ROLLOUT>(P, io, o, e, side, valid, lane, lane_global, kstep, lds);
   }
   if (valid && side == 0) {            // the env-level scalars
+  SS_PROFE(9);       // LDS refresh + hand-off to the emitting helper (or the inline output stage)
     float* Fo = P.fstate + e;
     if (advanced || do_reset) {
       store_cache(P, e, c);
@@ -970,6 +979,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
   }
   SS_MEMBAR();
 #if defined(SS_PROFILE_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+  SS_PROFE(10);      // env-level stores
   SS_PROF(13);
   if (lane == 0 && P.prof)
     for (int i = 0; i < 16; ++i) atomicAdd(P.prof + i, (unsigned long long)prof.t[i]);
