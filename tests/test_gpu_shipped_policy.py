@@ -27,3 +27,15 @@ def test_shipped_actor_walks_the_course_on_hip(env_id, kind, n, steps, mean_min,
           "end of the course; first-episode length mean %.0f" % (kind, n, stones.mean(), np.median(stones), stones.max(),
                                                                 100 * (stones >= 5).mean(), 100 * (stones >= 18).mean(), length.mean()))
     assert stones.mean() >= mean_min and np.median(stones) >= median_min
+
+
+def test_the_references_other_walker3d_actor_walks_on_hip():
+    """`Walker3DStepperEnv-v0_base.pt` (the reference's flat-terrain starting policy; tests/test_shipped_policy_walks.py) in the PRODUCT env."""
+    from steppingstone_amd.envs import SteppingStoneVecEnv
+    n = 1024
+    env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=31, device="cuda:0", return_numpy=False)
+    stones, length, alive = sa.walk(env, sa.load_actor("walker3d_base", "cuda:0"), 600, lambda o: o, n)
+    env.close()
+    print("_base on the MI355X, flat terrain, %d envs: stones beyond the start mean %.2f median %.1f max %.0f; %.0f %% reach 5 stones; "
+          "first-episode length mean %.0f" % (n, stones.mean(), np.median(stones), stones.max(), 100 * (stones >= 5).mean(), length.mean()))
+    assert stones.mean() >= 3.0 and (stones >= 5).mean() >= 0.2

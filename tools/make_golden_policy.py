@@ -17,7 +17,9 @@ sys.path.insert(0, ROOT)
 from steppingstone_amd import legacy_checkpoint as lc  # noqa: E402
 
 MODELS = "/root/reference/playground/models/"
-FILES = {"walker3d": "mocca_envs:Walker3DStepperEnv-v0_latest.pt", "mike": "mocca_envs:MikeStepperEnv-v0_latest.pt"}
+FILES = {"walker3d": "mocca_envs:Walker3DStepperEnv-v0_latest.pt", "mike": "mocca_envs:MikeStepperEnv-v0_latest.pt",
+         # round 6: the reference's OTHER Walker3D actor -- the flat-terrain policy its curriculum runs start from (playground/train.py:148-153)
+         "walker3d_base": "mocca_envs:Walker3DStepperEnv-v0_base.pt"}
 
 for kind, f in FILES.items():
     obj, storages = lc.read_legacy(MODELS + f)

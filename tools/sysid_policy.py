@@ -475,21 +475,27 @@ def main():
         def r4(v):
             if isinstance(v, (tuple, list)):
                 return [r4(u) for u in v]
+            if isinstance(v, bool):
+                return v
             return float("%.4g" % v)
         ov = {k: r4(v) for k, v in ov.items()}
         env_consts = {k: ov.pop(k) for k in list(ov) if k.startswith("env.")}
+        if PLAUSIBLE and FIXED_PLANK_B:
+            env_consts["env.plank"] = [PLANK_A, FIXED_PLANK_B]
         if args.stone_radius:
             env_consts["env.stone_radius"] = args.stone_radius        # the value adopted for BOTH robots (an env constant)
         _init_worker(args.kind)
         rows = {}
-        for cur, seed in ((0, 9), (0, 1234), (2, 1234), (5, 1234)):
-            _, d = rollout(args.kind, dict({k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}, **env_consts), n=128, steps=800,
-                           seed=seed, curriculum=cur, detail=True)
-            rows["curriculum %d seed %d" % (cur, seed)] = d
-            print("curriculum %d seed %4d: %s" % (cur, seed, json.dumps(d)))
+        for pol in _W["actors"]:
+            for cur, seed in ((0, 9), (0, 1234), (2, 1234), (3, 1234), (5, 1234)):
+                _, d = rollout(args.kind, dict({k: (tuple(v) if isinstance(v, list) else v) for k, v in ov.items()}, **env_consts), n=128, steps=800,
+                               seed=seed, curriculum=cur, detail=True, policy=pol)
+                rows["%s curriculum %d seed %d" % (pol, cur, seed)] = d
+                print("%s curriculum %d seed %4d: %s" % (pol, cur, seed, json.dumps(d)), flush=True)
         path = os.path.join(ROOT, "steppingstone_amd", "identified_%s.json" % args.kind)
         json.dump({"kind": args.kind, "what": "overrides of steppingstone_amd.model.DEFAULTS[kind] identified against the reference's shipped "
-                   "policy " + POLICY[args.kind] + " (tools/sysid_policy.py; DESIGN.md section 8)", "search_score": best.get("score"),
+                   "policy " + POLICY[args.kind] + " (tools/sysid_policy.py; DESIGN.md section 8)" + (
+                       "; round 6: inside the stated plausibility bounds of space_plausible(), stones = planks" if PLAUSIBLE else ""), "search_score": best.get("score"),
                    "search_generation": best.get("generation"), "evaluated_with_env_constants": env_consts, "shipped_policy_in_this_model": rows, "overrides": ov}, open(path, "w"), indent=1)
         print("wrote", path)
         return
