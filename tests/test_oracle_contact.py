@@ -102,7 +102,7 @@ def test_contact_stage_matches_independent_numpy(kind):
     print("contact stage %s: %d states without contact, %d single support, %d double support, %d on tilted stones, %d corners "
           "warm-started (%d of them from non-zero impulses); worst deviations %s" % (
               kind, count[0], count[1], count[2], tilted, warm_corners, warm_rows, {k: "%.1e" % v for k, v in worst.items()}))
-    assert count[1] >= 100 and count[2] >= 100 and tilted >= 100 and warm_rows >= 200
+    assert count[1] >= 100 and count[2] >= 100 and tilted >= 100 and warm_rows >= 150      # (composition of the sample; 188-260 depending on the robot numbers)
     assert all(v < 1e-9 for v in worst.values()), worst
 
 
