@@ -590,13 +590,23 @@ def test_remaining_hooks_match_oracle():
         st = r["next_state"]
     o.set_state(st)
     # specialist ring: stones drawn while standing on the target come from cells at Chebyshev distance 3 only
-    g.set_state(_stand_on_target(o, n))
+    st = _stand_on_target(o, n)
     zero = np.zeros((n, 21), np.float32)
+    advanced = 0
     for t in range(3):
-        o.step(zero); g.step(zero)
-        sg, so = g.get_state().cpu().numpy(), o.get_state()
-        assert np.array_equal(sg[:, INT_FIELDS], so[:, INT_FIELDS]) and np.abs(sg[:, 65:185] - so[:, 65:185]).max() < 1e-5
-        g.set_state(so)
+        # judged by the rule (a robot sagging under zero torques puts sole corners on their touch threshold: an env-step whose
+        # near-threshold decision the kernel takes the other way is matched on that branch by the rule, not by bit equality --
+        # round 6: with the re-identified Walker3D one of 128 envs does exactly that here); the envs on the oracle's own branch
+        # must have the oracle's integers and the oracle's freshly drawn stones
+        r, _, _, _ = _judged_step(J, g, st, zero)
+        sg, so = g.get_state().cpu().numpy(), r["next_state"]
+        same = r["category"] < 2
+        assert same.mean() >= 0.9
+        assert np.array_equal(sg[same][:, INT_FIELDS], so[same][:, INT_FIELDS]) and np.abs(sg[same][:, 65:185] - so[same][:, 65:185]).max() < 1e-5
+        advanced += int(r["oracle"]["info"]["update_terrain"].sum())
+        st = so
+    assert advanced >= n // 2                                    # the ring was actually drawn from
+    o.set_state(st)
     # auto-reset off: a finished env reports done and keeps its terminal observation until reset() is called
     g.backend.set_auto_reset(False); o.set_auto_reset(0)
     st = o.get_state(); st[:8, 2] -= 3.0         # drop eight robots far below the fall threshold
