@@ -549,7 +549,7 @@ struct DetectOut {
   int active;              // bit k: corner k touches a stone
   int cslot;               // 2 bits per corner: which stone slot
 };
-template <class Model>
+template <class Model, bool BRANCHFREE = true>
 SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], const Lds& L, DetectOut& o, FootReport& fr) {
   float Rf[3][3], pf[3];
   {
@@ -615,8 +615,18 @@ SSD void fk_detect(const float* cs8, const float* sn8, const float (&Rb)[3][3], 
         (void)lz;
         // the plank's footprint seen from above: the horizontal components of the in-plane offset along / across the stone's heading
         const float u = lx * hc[sl] + ly * hs_[sl], v = ly * hc[sl] - lx * hs_[sl];
-        const bool touch = (d < 0.f) && (d > -0.10f) && (fabsf(u) < kPlankA) && (fabsf(v) < kPlankB);
-        if (touch && d < best) { best = d; slot = sl; }      // the deeper stone wins, an exact tie goes to the stone visited first
+        // the deeper stone wins, an exact tie goes to the stone visited first.  Same predicate, two codings (measured per variant,
+        // profiles/r06_ab_disc_vs_plank_variants.txt): with && the compiler nests exec-mask branches around u and v -- the faster form
+        // where a dedicated helper wavefront runs the detection beside the main one (three helpers), 3 % slower where the detection
+        // sits on the longest path (plain kernel: the main wavefront; one helper: the helper that does everything)
+        if constexpr (BRANCHFREE) {
+          const bool touch = (d < 0.f) & (d > -0.10f) & (fabsf(u) < kPlankA) & (fabsf(v) < kPlankB) & (d < best);
+          best = touch ? d : best;
+          slot = touch ? sl : slot;
+        } else {
+          const bool touch = (d < 0.f) && (d > -0.10f) && (fabsf(u) < kPlankA) && (fabsf(v) < kPlankB);
+          if (touch && d < best) { best = d; slot = sl; }
+        }
       }
       o.pen[k] = -best;
       // on the target = a corner CARRIED by stone n (round 6; rounds 1-5: within stone n's disc, whichever stone carried it)
@@ -728,7 +738,7 @@ __device__ __forceinline__ void helper_substep(int helper, const Lds& L, Extra&&
     quat_rot(quat, Rb);
     DetectOut det;
     FootReport fr;
-    fk_detect<Model>(cs8, sn8, Rb, L, det, fr);
+    fk_detect<Model, (HELPERS < 3)>(cs8, sn8, Rb, L, det, fr);
     const int flags = det.active | (det.cslot << 4) | (fr.contact << 12) | (fr.on_target << 13);
     L.hs(kHandDet + 13) = __builtin_bit_cast(float, flags);
 #pragma unroll
