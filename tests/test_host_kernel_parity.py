@@ -75,14 +75,14 @@ def test_steps_of_a_walking_policy_on_turned_and_tilted_stones_match_oracle(kind
     o.set_curriculum(3)
     obs = o.reset()
     actor = sa.load_actor(kind)
-    for t in range(170):
+    for t in range(110):           # (first episodes: both robots are on their third / fourth stone; Mike falls soon after at this level)
         with torch.no_grad():
             obs, _, _, _ = o.step(actor(torch.from_numpy(obs)).numpy())
     st = o.get_state()
     terr = st[:, 65:185].reshape(n, 20, 6)
     nidx = st[:, ol.S_N].astype(int)
     turned = np.abs(terr[np.arange(n), nidx, 3]) > 0.03
-    assert turned.sum() >= n // 8, "the sample does not exercise turned stones"      # (Mike falls early at this level: 8 of 48)
+    assert turned.sum() >= n // 2, "the sample does not exercise turned stones"
     bad = total = advanced = contacts = 0
     for t in range(14):
         st = o.get_state()
