@@ -294,7 +294,9 @@ def _humanoid_at_density(P):
 def identified(kind):
     """The numbers identified against the reference's SHIPPED policy for this robot (tools/sysid_policy.py --emit ->
     steppingstone_amd/identified_<kind>.json; DESIGN.md section 8, docs/PHYSICS.md section 2): overrides of DEFAULTS[kind] under which the
-    deterministic `playground/models/*_latest.pt` actor walks the stepping-stone course.  {} if no file is present."""
+    deterministic `playground/models/*_latest.pt` actor walks the stepping-stone course.  Round 6: re-identified inside stated
+    plausibility bounds, on plank-shaped stones, Walker3D with the reference's `_base.pt` actor in the score as well (DESIGN.md section
+    8.3; tools/gen_model_tables.py: assert_plausible checks the result).  {} if no file is present."""
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "identified_%s.json" % kind)
