@@ -14,6 +14,9 @@
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
 #pragma once
 #include "ss_dynamics.hpp"
+#ifndef SS_SPLIT_ACTION_PHILOX
+#define SS_SPLIT_ACTION_PHILOX 1
+#endif
 #ifndef SS_EMIT_ON_LAST_HELPER
 #define SS_EMIT_ON_LAST_HELPER 1
 #endif
@@ -541,7 +544,10 @@ SSD void emit_outputs(const Params& P, const StepIO& io, const StepOut& o, int e
 // place of the detection's Rf / pen, which that variant does not use, and the two spare words), everything else is the state in
 // LDS region B (refreshed after a reset).  Helper 1 works while the main wavefront is already in the next
 // control step (between barriers #0b and #1 of its first substep; the state in LDS changes at that substep's end only).
-constexpr bool out_offload(int helpers, bool rollout) { return rollout && helpers >= 3; }   // (one launch per step: 0.0697 vs 0.0687 ms inline)
+#ifndef SS_STEP_EMIT_OFFLOAD
+#define SS_STEP_EMIT_OFFLOAD 0
+#endif
+constexpr bool out_offload(int helpers, bool rollout) { return (rollout || SS_STEP_EMIT_OFFLOAD) && helpers >= 3; }   // (one launch per step: 0.0697 vs 0.0687 ms inline, round 3)
 constexpr int kHandOut = kHandDet, kHandOut2 = kHandFloats;     // 13 + 2 words
 static_assert(kHandOut2 + 2 <= kHandSlots * 4, "hand-off region");
 #if !defined(SS_HOST_HARNESS)
@@ -589,8 +595,26 @@ __device__ __forceinline__ void emit_from_handoff(const Params& P, const StepIO&
 template <class Write>
 SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t tt, Write&& write) {
   uint32_t ra[6][4];
+#if SS_SPLIT_ACTION_PHILOX
+  {   // three of the six blocks per lane of the pair, exchanged (integer-exact; like the reset noise): 300 instructions less per step
+      // wherever the main wavefront draws the actions itself
+    uint32_t mine[3][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      philox4x32_10(6u * tt + (side ? 3u : 0u) + b, 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, mine[b]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t other = xchg_u32(mine[b][i]);
+        ra[b][i] = side ? other : mine[b][i];
+        ra[3 + b][i] = side ? mine[b][i] : other;
+      }
+  }
+#else
 #pragma unroll
   for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, ra[b]);
+#endif
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
     constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
@@ -941,6 +965,9 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
     for (int i = 0; i < 3; ++i) { L.hs(kHandOut + 3 + i) = c.p[1][i]; L.hs(kHandOut + 8 + i) = c.p[2][i]; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) { L.hs(kHandOut + 6 + i) = c.tilt[1][i]; L.hs(kHandOut + 11 + i) = c.tilt[2][i]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (!ROLLOUT) __syncthreads();      // one launch per step: the helper emits NOW, beside this wavefront's env-level stores
+#endif
   } else {
     StepOut o;
 #pragma unroll
@@ -986,7 +1013,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
 #endif
   }   // control steps of this launch
 #if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (out_offload(HELPERS, ROLLOUT)) __syncthreads();   // helper 1 emits the last step's outputs
+  if constexpr (out_offload(HELPERS, ROLLOUT) && ROLLOUT) __syncthreads();   // a helper emits the last step's outputs
 #endif
 }
 
@@ -1047,6 +1074,10 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void step_kernel_helped(P
     const Lds L{lds, lane};
 #pragma unroll 1
     for (int k = 0; k < SS_NUM_SUBSTEPS; ++k) helper_substep<Model, HELPERS>(wave - 1, L, [](int) {});
+    if constexpr (out_offload(HELPERS, false)) {     // (tuning option) the output stage on a helper, beside the main wavefront's own stores
+      __syncthreads();
+      if (wave == HELPERS) emit_from_handoff<Model, false>(P, io, L, lane, blockIdx.x * kWave + lane, 0, lds);
+    }
   }
 }
 // K control steps per launch (ss_rollout_random): same code, state resident in LDS between the steps
