@@ -14,8 +14,11 @@
 //   prob   [121] float shared grid, or [121][Npad] per-env grids
 #pragma once
 #include "ss_dynamics.hpp"
+// Two tuning options measured in round 6 and NOT adopted (profiles/r06_ab_disc_vs_plank_variants.txt): the benchmark actions' six Philox
+// blocks split between the lanes of a pair (-0.4 % / -0.6 % at 4096 envs, +0.9 % in the plain K-step kernel), and the one-launch-per-
+// step kernel's output stage on a helper wavefront (SS_STEP_EMIT_OFFLOAD below: no gain, as in round 3).
 #ifndef SS_SPLIT_ACTION_PHILOX
-#define SS_SPLIT_ACTION_PHILOX 1
+#define SS_SPLIT_ACTION_PHILOX 0
 #endif
 #ifndef SS_EMIT_ON_LAST_HELPER
 #define SS_EMIT_ON_LAST_HELPER 1
