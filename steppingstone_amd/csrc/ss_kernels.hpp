@@ -595,11 +595,10 @@ __device__ __forceinline__ void emit_from_handoff(const Params& P, const StepIO&
 
 // Benchmark actions of control step tt for this lane's half of env e (PHYSICS.md 5: six Philox blocks per env and step, 21 of the
 // 24 words -> U(-1,1)), in the lane's own (mirrored) world.
-template <class Write>
+template <bool SPLIT = false, class Write>
 SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t tt, Write&& write) {
   uint32_t ra[6][4];
-#if SS_SPLIT_ACTION_PHILOX
-  {   // three of the six blocks per lane of the pair, exchanged (integer-exact; like the reset noise): 300 instructions less per step
+  if constexpr (SPLIT && SS_SPLIT_ACTION_PHILOX) {   // three of the six blocks per lane of the pair, exchanged (integer-exact; like the reset noise): 300 instructions less per step
       // wherever the main wavefront draws the actions itself
     uint32_t mine[3][4];
 #pragma unroll
@@ -613,11 +612,10 @@ SSD void random_actions_half(const Params& P, int e, int side, float m, uint32_t
         ra[b][i] = side ? other : mine[b][i];
         ra[3 + b][i] = side ? mine[b][i] : other;
       }
-  }
-#else
+  } else {
 #pragma unroll
-  for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, ra[b]);
-#endif
+    for (int b = 0; b < 6; ++b) philox4x32_10(6u * tt + b, 1u, P.env_offset + ((uint32_t)e & P.id_mask), 0u, P.seed_lo, P.seed_hi, ra[b]);
+  }
   static_for<0, NH>([&](auto Kc) {
     constexpr int k = decltype(Kc)::value, jr = kHalf[k];
     constexpr int jl = jr < 3 ? jr : (jr < 8 ? jr + 5 : jr + 4);
@@ -720,7 +718,7 @@ SSD void step_env(const Params& P, const StepIO& io, int lane_global, int lane, 
         drawn = true;
       }
     }
-    if (!drawn) random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep, [&](int k, float a) { L.s(S_ACT + k) = a; });
+    if (!drawn) random_actions_half<!(HELPERS == 0 && ROLLOUT)>(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep, [&](int k, float a) { L.s(S_ACT + k) = a; });
   } else {
     static_for<0, NH>([&](auto Kc) {
       constexpr int k = decltype(Kc)::value, jr = kHalf[k];
@@ -1119,7 +1117,7 @@ __global__ __launch_bounds__(kWave * (1 + HELPERS), 1) void rollout_kernel_helpe
           constexpr int kActHelper = SS_EMIT_ON_LAST_HELPER && out_offload(HELPERS, true) ? 1 : HELPERS - 1;
           constexpr int kEmitHelper = SS_EMIT_ON_LAST_HELPER && out_offload(HELPERS, true) ? HELPERS - 1 : 1;
           if (HELPERS > 1 && helper == kActHelper && kstep + 1 < io.nsteps)
-            random_actions_half(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
+            random_actions_half<true>(P, e, side, m, (uint32_t)io.t + (uint32_t)kstep + 1u, [&](int j, float a) { L.hs(kHandAct + j) = a; });
           // the previous control step's outputs
           if (out_offload(HELPERS, true) && helper == kEmitHelper && kstep > 0) emit_from_handoff<Model, true>(P, io, L, lane, lane_global, kstep - 1, lds);
         });
