@@ -26,3 +26,19 @@ def test_identified_numbers_are_what_the_specification_evaluates():
         assert abs(m["friction"] - ident["friction"]) < 1e-12 and m["mass"].sum() != prior["mass"].sum()
     ec = model.env_constants()
     assert ec["stone_plank_half_length"] == 0.30 and 0.30 <= ec["stone_plank_half_width"] <= 0.60      # a plank that cannot overlap its neighbour
+
+
+def test_the_identified_robots_pass_the_plausibility_assertions():
+    """the compiled numbers describe a robot -- nominal pose strictly inside the joint ranges (the reset clip never pins
+    a joint), sole = the foot box's bottom face 4-10 cm below the ankle, friction and mass multipliers inside their stated bounds
+    (tools/gen_model_tables.py: assert_plausible)."""
+    import numpy as np
+    import gen_model_tables as gen
+    from steppingstone_amd import model
+    for kind in ("walker3d", "mike"):
+        assert gen.assert_plausible(kind) is True, "%s: no round-6 identified file" % kind
+        m = model.build(kind)
+        lo, hi = m["range"][:, 0] + 0.02, m["range"][:, 1] - 0.02                 # PHYSICS.md 7: q = clip(q0 + 0.05 (2u - 1), lo + 0.02, hi - 0.02)
+        assert (m["q0"] - 0.05 >= lo - 1e-9).all() and (m["q0"] + 0.05 <= hi + 1e-9).all()
+        c = m["corners"]
+        assert np.ptp(c[:, 2]) == 0 and -0.10 <= c[0, 2] <= -0.04
