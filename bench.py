@@ -423,10 +423,12 @@ def main():
     # The timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  A region shorter than
     # 50 ms (the driver runs --steps 20: 1 ms) is one noisy sample, so it is then repeated -- every repeat is again exactly K
     # steps, continuing the rollout -- and the MEDIAN region is reported (min / max beside it).  Round 6: at least
-    # 9 regions AND until the regions add up to MIN_TIMED_S = 1 s of timed work (VERDICT asked for >= 0.1 s; at most MAX_REPEATS), so that the driver's gpu_busy
-    # sampler sees the GPU working and the median rests on ~1000 regions instead of 9; `repeats` and `timed_region_s` say what was done.
+    # 9 regions AND until the regions add up to MIN_TIMED_S = 5 s of timed work (VERDICT asked for >= 0.1 s; the whole default run is ~20 s, 12 of them the CPU baseline; at most MAX_REPEATS), so that the driver's gpu_busy
+    # sampler sees the GPU working and the median rests on ~5000 regions instead of 9; `repeats` and `timed_region_s` say what was done.
     # The stop rule uses the max-over-ranks times, so every rank runs the same number of regions.
-    REPEAT_BELOW_S, MIN_REPEATS, MIN_TIMED_S, MAX_REPEATS = 0.05, 9, 1.0, 2000
+    REPEAT_BELOW_S, MIN_REPEATS, MIN_TIMED_S, MAX_REPEATS = 0.05, 9, 5.0, 20000
+    if test_transport:
+        MIN_TIMED_S = 0.2          # a functional run of the N > 1 path (all ranks on one GPU): never a measurement
     t_next = W
     samples = []
     # The two HIP events that measure the kernel time for the roofline are instrumentation INSIDE the timed region (two marker packets

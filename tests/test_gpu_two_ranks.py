@@ -127,7 +127,7 @@ def test_bench_two_rank_path_runs_end_to_end_on_one_gpu():
     # the self-proof of the exchange and the policy-in-the-loop row (round 3)
     assert d["gather_verified"] is True and d["rccl_ranks"] == 2 and "rccl_version" in d and d["transport"] == "gloo"
     assert d["per_step_gather"]["value"] > 0 and d["policy_in_the_loop"]["ms_per_step"] == d["per_step_gather"]["ms_per_step"]
-    assert d["repeats"] >= 9 and d["timed_region_s"] >= 1.0 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert d["repeats"] >= 9 and d["timed_region_s"] >= 0.2 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     # round 6: the per-step exchange (north_star's / SURVEY 8d-4's shape) is a first-class value beside the chunked one, and the line carries
     # the process group's own view
     assert d["value_per_step_exchange"] == d["per_step_gather"]["value"] and d["ms_per_step_per_step_exchange"] == d["per_step_gather"]["ms_per_step"]
