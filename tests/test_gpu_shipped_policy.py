@@ -34,8 +34,8 @@ def test_the_references_other_walker3d_actor_walks_on_hip():
     from steppingstone_amd.envs import SteppingStoneVecEnv
     n = 1024
     env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=31, device="cuda:0", return_numpy=False)
-    stones, length, alive = sa.walk(env, sa.load_actor("walker3d_base", "cuda:0"), 600, lambda o: o, n)
+    stones, length, alive = sa.walk(env, sa.load_actor("walker3d_base", "cuda:0"), 900, lambda o: o, n)
     env.close()
     print("_base on the MI355X, flat terrain, %d envs: stones beyond the start mean %.2f median %.1f max %.0f; %.0f %% reach 5 stones; "
           "first-episode length mean %.0f" % (n, stones.mean(), np.median(stones), stones.max(), 100 * (stones >= 5).mean(), length.mean()))
-    assert stones.mean() >= 3.0 and (stones >= 5).mean() >= 0.2
+    assert stones.mean() >= 8.0 and (stones >= 5).mean() >= 0.6

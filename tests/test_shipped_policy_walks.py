@@ -36,10 +36,10 @@ def test_the_references_other_walker3d_actor_walks_too():
     """Round 6: `Walker3DStepperEnv-v0_base.pt` is the flat-terrain policy the reference's curriculum runs start from
     (playground/train.py:148-153) -- a different actor from `_latest` (`_best` carries `_latest`'s weights), less robust and so the
     sharper probe of flat-terrain physics.  Rounds 1-4: 0.0 stones; round 5 (fit to `_latest` alone): 2.0; round 6 (joint fit, `_base`
-    on flat terrain in the score): 4.3-4.8 stones on other seeds, 36-40 % of the episodes beyond 5 stones.  A regression guard, set below."""
+    on flat terrain in the score; stage 3): 12.1-13.1 stones on other seeds (median 13-16), 87-88 % of the episodes beyond 5 stones.  A regression guard, set below."""
     n = 64
     env = SteppingStoneVecEnv("Walker3DStepperEnv-v0", n, seed=31, return_numpy=False, backend=OracleBackend("walker3d", n, 31))
-    stones, length, alive = sa.walk(env, sa.load_actor("walker3d_base"), 500, lambda o: o, n)
+    stones, length, alive = sa.walk(env, sa.load_actor("walker3d_base"), 900, lambda o: o, n)      # (it walks the course more slowly than `_latest`: ~450 steps and more)
     print("_base in the CPU oracle, flat terrain, %d envs: stones beyond the start mean %.2f median %.1f max %.0f; %.0f %% reach 5 stones" % (
         n, stones.mean(), np.median(stones), stones.max(), 100 * (stones >= 5).mean()))
-    assert stones.mean() >= 3.0 and (stones >= 5).mean() >= 0.2
+    assert stones.mean() >= 8.0 and (stones >= 5).mean() >= 0.6
