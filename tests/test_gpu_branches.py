@@ -256,6 +256,11 @@ def test_rollout_kernel_is_bitwise_equal_to_single_step_launches(n, env_id):
             e = gpu_env(env_id, n, seed=9, numpy_mode=False)
             e.update_curriculum(5)
             e.reset()
+            # every other env starts over its target stone (stone 1), so that target advances and stone draws happen whatever the robot
+            # numbers are (round 6: under random actions the re-identified Walker3D no longer stumbles onto stone 1 often enough by itself)
+            st0 = e.get_state().clone()
+            st0[::2, 0] = st0[::2, 65 + 6]
+            e.set_state(st0)
             e.rollout_random(130, t0=3, steps_per_launch=spl)
             torch.cuda.synchronize()
             outs.append((e._obs.clone(), e._rew.clone(), e._done.clone(), e._info.clone(), e.get_state().clone()))
@@ -266,7 +271,9 @@ def test_rollout_kernel_is_bitwise_equal_to_single_step_launches(n, env_id):
         else:
             os.environ["SS_HELPERS"] = old
     assert outs[0][4][:, 61].max() < 130            # everybody was reset at least once
-    assert outs[0][4][:, 59].max() >= 2             # some targets advanced
+    # some targets advanced: a reset draws 6 Philox blocks of the env stream, a target advance 1 -- a block counter that is not a multiple
+    # of 6 has seen an advance (the final target index would not do: an env that advanced has usually fallen and been reset since)
+    assert (outs[0][4][:, 62].long() % 6 != 0).sum() >= n // 50
     for k in range(1, len(outs)):
         for a, b in zip(outs[0], outs[k]):
             assert torch.equal(a, b), "variant %d differs" % k
