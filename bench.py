@@ -246,7 +246,15 @@ def launch_shape(W, K, spl, ms_per_step, prewarm=0):
         return out
     warm, timed = sizes(W), sizes(K)
     every = ([prewarm] if spl > 1 and prewarm else []) + warm + timed     # the clock-ramp launch runs the same kernel
-    return {"launch_steps": {"prewarm": prewarm, "warmup": warm, "timed": timed},
+    def rle(xs):           # run-length form [[steps per launch, launches], ...]: the driver's shape repeats its 20-step launch thousands of times
+        out = []
+        for x in xs:
+            if out and out[-1][0] == x:
+                out[-1][1] += 1
+            else:
+                out.append([x, 1])
+        return out
+    return {"launch_steps": {"prewarm": prewarm, "warmup": warm, "timed_steps_x_launches": rle(timed)},
             "rocprofv3_stats_average_ms_expected": ms_per_step * sum(every) / max(len(every), 1)}
 
 
