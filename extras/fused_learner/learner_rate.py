@@ -2,10 +2,11 @@
 sizes, next to the torch (autograd + Adam, hipGraph) step.  FLOPs per sample: forward 2 x (weights of actor + critics),
 backward data the same minus the input layers, backward weights the same as forward."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-from steppingstone_amd import fused_ppo, ppo
+import fused_ppo
+from steppingstone_amd import ppo
 dev = torch.device("cuda:0")
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 R = 131072

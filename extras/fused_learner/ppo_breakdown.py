@@ -1,9 +1,10 @@
 """Where a PPO update spends its time (one GPU, Mike, 4096 envs, 32-step rollouts): graph rollout, GAE, learner."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-from steppingstone_amd import fused_ppo, ppo
+import fused_ppo
+from steppingstone_amd import ppo
 from steppingstone_amd.envs import SteppingStoneVecEnv
 dev = torch.device("cuda:0")
 n, T = 4096, 32

@@ -1,9 +1,10 @@
 """PPO end-to-end frames/s (BASELINE configs[4] shape on one GPU: Mike, curriculum on, 32-step rollouts, 10 epochs):
 eager vs hipGraph and minibatch sizes; steady state = updates 4..10 (after warm-up and graph capture)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
+import fused_ppo
 from steppingstone_amd import ppo
 from steppingstone_amd.envs import SteppingStoneVecEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -17,7 +18,7 @@ for use_graph, mb, learner in rows:
     def log(st):
         torch.cuda.synchronize()
         stamps.append((time.time(), st["total_num_steps"], st["mean_rew"]))
-    ac, hist = ppo.train(envs, 10, num_steps=32, ppo_epoch=10, mini_batch_size=mb, log=log, use_graph=use_graph, learner=learner,
+    ac, hist = ppo.train(envs, 10, num_steps=32, ppo_epoch=10, mini_batch_size=mb, log=log, use_graph=use_graph, agent_factory=(fused_ppo.FusedPPO if learner == "fused" else None),
                           use_mirror=mirror)
     fps = (stamps[-1][1] - stamps[3][1]) / (stamps[-1][0] - stamps[3][0])
     print("%d envs  mirror=%d graph=%d  learner=%-5s minibatch %5d: %7.0f frames/s steady state, mean episode return %.1f -> %.1f" %
